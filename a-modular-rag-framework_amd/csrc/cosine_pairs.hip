@@ -1,0 +1,68 @@
+// a1/a2: one query against n candidate vectors, fp64 on the device.
+// Replaces DenseReranker._cosine x N (app/modules/retrieval/retrieval_backend.py:192-197,245):
+// out[i] = dot / (|q| |c_i|), 0.0 when either norm is zero.  One wave per candidate,
+// coalesced fp64 loads, shuffle reduction; HBM-bound: reads (n+1)*dim*8 bytes.
+#include "common.h"
+
+namespace mrag {
+
+__global__ __launch_bounds__(256) void cosine_f64_kernel(const double* __restrict__ q, const double* __restrict__ c,
+                                                         int64_t n, int dim, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* v = c + row * (int64_t)dim;
+  double dot = 0.0, qq = 0.0, vv = 0.0;
+  for (int i = lane; i < dim; i += 64) {
+    const double a = q[i], b = v[i];
+    dot += a * b;
+    qq += a * a;
+    vv += b * b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dot += __shfl_xor(dot, off);
+    qq += __shfl_xor(qq, off);
+    vv += __shfl_xor(vv, off);
+  }
+  if (lane == 0) {
+    const double na = sqrt(qq), nb = sqrt(vv);
+    out[row] = (na != 0.0 && nb != 0.0) ? dot / (na * nb) : 0.0;
+  }
+}
+
+}  // namespace mrag
+
+using namespace mrag;
+
+extern "C" int mrag_cosine_f64(int device, const double* query, const double* cands, int64_t n, int dim,
+                               double* out_scores, int is_device, void* stream_) {
+  if (n < 0 || dim <= 0) return fail(MRAG_ERR_INVALID, "bad shape n=%lld dim=%d", (long long)n, dim);
+  if (n == 0) return MRAG_OK;
+  if (!query || !cands || !out_scores) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  MRAG_TRY(use_device(device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const double *dq = query, *dc = cands;
+  double* dout = out_scores;
+  void* tmp = nullptr;
+  if (!is_device) {
+    const size_t qb = (size_t)dim * 8, cb = (size_t)n * dim * 8, ob = (size_t)n * 8;
+    MRAG_HIP(hipMalloc(&tmp, qb + cb + ob));
+    char* base = (char*)tmp;
+    hipError_t e1 = hipMemcpyAsync(base, query, qb, hipMemcpyHostToDevice, stream);
+    hipError_t e2 = hipMemcpyAsync(base + qb, cands, cb, hipMemcpyHostToDevice, stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(tmp); return fail(MRAG_ERR_HIP, "H2D copy failed"); }
+    dq = (const double*)base;
+    dc = (const double*)(base + qb);
+    dout = (double*)(base + qb + cb);
+  }
+  hipLaunchKernelGGL(cosine_f64_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, dq, dc, n, dim, dout);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !is_device) {
+    e = hipMemcpyAsync(out_scores, dout, (size_t)n * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  if (tmp) (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(MRAG_ERR_HIP, "cosine_f64 failed: %s", hipGetErrorString(e));
+  return MRAG_OK;
+}

@@ -1,0 +1,171 @@
+"""HBM-resident dense indexes over the C ABI (include/mrag.h).
+
+``DenseIndex`` is the corpus-scale form of the reference's dense scoring
+(app/modules/retrieval/retrieval_backend.py:245,371-372: cosine every candidate, sort
+descending, truncate): rows are L2-normalised and rounded once to fp16/bf16, kept in
+HBM, and every search is one fused MFMA similarity + top-k pass.  Tie-break: score
+descending, then row ascending.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+_NP_DT = {np.dtype(np.float32): N.MRAG_F32, np.dtype(np.float16): N.MRAG_F16, np.dtype(np.float64): N.MRAG_F64}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _torch_dtype_code(t) -> int:
+    import torch
+    return {torch.float32: N.MRAG_F32, torch.float16: N.MRAG_F16, torch.bfloat16: N.MRAG_BF16,
+            torch.float64: N.MRAG_F64}[t.dtype]
+
+
+def _as_buffer(x, dim: int):
+    """-> (keepalive, pointer, n_rows, dtype_code, is_device)."""
+    if _is_torch(x):
+        if x.dim() != 2 or x.shape[1] != dim:
+            raise ValueError(f"expected [n, {dim}] rows, got {tuple(x.shape)}")
+        x = x.contiguous()
+        if x.is_cuda:
+            return x, x.data_ptr(), x.shape[0], _torch_dtype_code(x), 1
+        if x.dtype.is_floating_point and str(x.dtype) == "torch.bfloat16":
+            return x, x.data_ptr(), x.shape[0], N.MRAG_BF16, 0
+        x = x.numpy()
+    a = np.ascontiguousarray(x)
+    if a.ndim != 2 or a.shape[1] != dim:
+        raise ValueError(f"expected [n, {dim}] rows, got {a.shape}")
+    if a.dtype not in _NP_DT:
+        a = a.astype(np.float32)
+    return a, a.ctypes.data, a.shape[0], _NP_DT[a.dtype], 0
+
+
+def _stream_ptr(stream) -> Optional[int]:
+    if stream is None:
+        return None
+    return int(getattr(stream, "cuda_stream", stream))
+
+
+class DenseIndex:
+    """Brute-force cosine (or inner-product) top-k index on one GPU."""
+
+    def __init__(self, dim: int, metric: str = "cosine", dtype: str = "f16", device: int = 0):
+        self._lib = N.load()
+        self.dim, self.metric, self.dtype, self.device = int(dim), metric, dtype, int(device)
+        h = C.c_uint64(0)
+        N.check(self._lib.mrag_index_create(self.dim, N.METRIC_COSINE if metric == "cosine" else N.METRIC_IP,
+                                            N.MRAG_F16 if dtype == "f16" else N.MRAG_BF16, self.device, C.byref(h)))
+        self._h = h
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mrag_index_destroy(self._h)
+            self._h = C.c_uint64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_int64(0)
+        N.check(self._lib.mrag_index_size(self._h, C.byref(n)))
+        return n.value
+
+    # -- build ----------------------------------------------------------------------------
+    def reserve(self, n_rows: int):
+        N.check(self._lib.mrag_index_reserve(self._h, int(n_rows)))
+
+    def set_id_base(self, base: int):
+        N.check(self._lib.mrag_index_set_id_base(self._h, int(base)))
+
+    def add(self, rows, normalize: Optional[bool] = None, stream=None):
+        """Append rows ([n, dim] numpy / torch, host or device).  ``normalize`` defaults to
+        True for the cosine metric; pass False for rows that are already normalised and
+        rounded (they are then stored bit-for-bit when their dtype is the storage dtype)."""
+        if normalize is None:
+            normalize = self.metric == "cosine"
+        keep, ptr, n, dt, is_dev = _as_buffer(rows, self.dim)
+        if is_dev and stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device)   # stream-ordered with the producer of `rows`
+        N.check(self._lib.mrag_index_add(self._h, ptr, n, dt, int(bool(normalize)), is_dev, _stream_ptr(stream)))
+        del keep
+
+    def rows(self, row0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = len(self) - row0 if n is None else n
+        out = np.empty((n, self.dim), dtype=np.float32)
+        N.check(self._lib.mrag_index_get_rows(self._h, int(row0), int(n), out.ctypes.data, 0, None))
+        return out
+
+    # -- search ---------------------------------------------------------------------------
+    def search(self, queries, k: int, normalize: Optional[bool] = None, stream=None, out=None
+               ) -> Tuple["np.ndarray", "np.ndarray"]:
+        """-> (scores [nq,k] fp32 descending, ids [nq,k] int64; (-inf, -1) past the corpus).
+
+        Host queries give numpy results (the call returns when they have landed); CUDA
+        tensors give CUDA tensors, written asynchronously on ``stream`` (default: torch's
+        current stream).  ``out=(scores, ids)`` reuses caller tensors."""
+        if normalize is None:
+            normalize = self.metric == "cosine"
+        keep, ptr, nq, dt, is_dev = _as_buffer(queries, self.dim)
+        if is_dev:
+            import torch
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device)
+            if out is None:
+                sc = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
+                ids = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
+            else:
+                sc, ids = out
+            N.check(self._lib.mrag_index_search(self._h, ptr, nq, dt, int(bool(normalize)), 1, int(k),
+                                                sc.data_ptr(), ids.data_ptr(), 1, _stream_ptr(stream)))
+            return sc, ids
+        sc = np.empty((nq, k), dtype=np.float32)
+        ids = np.empty((nq, k), dtype=np.int64)
+        N.check(self._lib.mrag_index_search(self._h, ptr, nq, dt, int(bool(normalize)), 0, int(k),
+                                            sc.ctypes.data, ids.ctypes.data, 0, _stream_ptr(stream)))
+        return sc, ids
+
+    def last_timing_ms(self) -> Tuple[float, float]:
+        """(fused similarity+top-k kernel ms, whole search ms) of the last search, from
+        hipEvents recorded on the launch stream."""
+        g, t = C.c_float(0), C.c_float(0)
+        N.check(self._lib.mrag_index_last_timing(self._h, C.byref(g), C.byref(t)))
+        return g.value, t.value
+
+
+def cosine_f64(query, cands, device: int = 0) -> np.ndarray:
+    """One query against n candidates, fp64 on the GPU -- the arithmetic of
+    ``DenseReranker._cosine`` (retrieval_backend.py:192-197) for every candidate at once."""
+    q = np.ascontiguousarray(query, dtype=np.float64).reshape(-1)
+    c = np.ascontiguousarray(cands, dtype=np.float64)
+    if c.ndim != 2 or c.shape[1] != q.shape[0]:
+        raise ValueError("dimension mismatch")
+    out = np.empty(c.shape[0], dtype=np.float64)
+    N.check(N.load().mrag_cosine_f64(device, q.ctypes.data, c.ctypes.data, c.shape[0], c.shape[1],
+                                     out.ctypes.data, 0, None))
+    return out
+
+
+def topk_merge(scores: np.ndarray, ids: np.ndarray, nthreads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Host merge of per-shard partial top-k: scores/ids [nparts, nq, k] -> [nq, k]
+    ordered by (score desc, id asc).  Runs on the CPU (C++ threads)."""
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    i = np.ascontiguousarray(ids, dtype=np.int64)
+    if s.ndim != 3 or s.shape != i.shape:
+        raise ValueError("expected matching [nparts, nq, k] arrays")
+    nparts, nq, k = s.shape
+    os_, oi = np.empty((nq, k), dtype=np.float32), np.empty((nq, k), dtype=np.int64)
+    N.check(N.load().mrag_topk_merge(s.ctypes.data, i.ctypes.data, nparts, nq, k, os_.ctypes.data,
+                                     oi.ctypes.data, int(nthreads)))
+    return os_, oi

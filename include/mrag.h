@@ -1,0 +1,150 @@
+/*
+ * mrag.h -- C ABI of the MI355X-native dense-retrieval hot path (libmrag_hip.so).
+ *
+ * Drop-in boundary for the embedding + cosine top-k path of
+ * AndyUkJ/A-Modular-RAG-Framework.  The reference is pure Python and has no FFI of
+ * its own; each entry point below names the reference code it replaces
+ * (paths relative to the reference checkout).  Binding a maintainer would add:
+ * INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - every function returns an int status: MRAG_OK (0) or a negative MRAG_ERR_*;
+ *     mrag_last_error() returns a thread-local message for the last failure.
+ *   - handles are opaque uint64 values; 0 is never a valid handle.
+ *   - all buffers are caller-owned, plain pointers + sizes.  A pointer argument is
+ *     a HOST pointer unless the matching *_is_device flag is non-zero, in which
+ *     case it is a device pointer on the handle's device (e.g. a torch tensor's
+ *     data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls
+ *     with device outputs are asynchronous on that stream; calls with host outputs
+ *     return after the results have landed.
+ *   - one call in flight per handle (the reference is single-threaded).
+ *   - there is NO CPU fallback: without a usable GPU every compute entry point
+ *     fails with MRAG_ERR_NO_DEVICE.
+ */
+#ifndef MRAG_H_
+#define MRAG_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRAG_ABI_VERSION 1
+
+#define MRAG_OK 0
+#define MRAG_ERR_INVALID (-1)     /* bad argument / bad handle */
+#define MRAG_ERR_NO_DEVICE (-2)   /* no HIP device, or device index out of range */
+#define MRAG_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define MRAG_ERR_OOM (-4)         /* device or host allocation failed */
+#define MRAG_ERR_UNSUPPORTED (-5) /* valid request this build cannot serve (e.g. k too large) */
+
+typedef uint64_t mrag_handle;
+
+enum mrag_dtype { MRAG_F32 = 0, MRAG_F16 = 1, MRAG_BF16 = 2, MRAG_F64 = 3 };
+enum mrag_metric { MRAG_METRIC_COSINE = 0, MRAG_METRIC_IP = 1 };
+enum mrag_pool { MRAG_POOL_MEAN = 0, MRAG_POOL_CLS = 1 };
+
+/* ---- library ------------------------------------------------------------------ */
+int mrag_abi_version(void);
+const char* mrag_last_error(void);
+int mrag_device_count(int* out_count);
+
+/* ---- a1/a2: pairwise cosine, replaces DenseReranker._cosine x N ------------------
+ * app/modules/retrieval/retrieval_backend.py:192-197 (formula, zero/length guards)
+ * and :245 (one query against every candidate).  fp64 on the device:
+ * out[i] = dot(q, c_i) / (|q| * |c_i|), 0.0 when either norm is 0.  `cands` is
+ * row-major [n, dim] fp64.  A dimension mismatch between query and candidates is the
+ * caller's to map to 0.0 (the reference compares list lengths, :193). */
+int mrag_cosine_f64(int device, const double* query, const double* cands, int64_t n, int dim,
+                    double* out_scores, int is_device, void* stream);
+
+/* ---- a7 at corpus scale: brute-force cosine / inner-product top-k ----------------
+ * Replaces "score every candidate, sort descending, truncate" --
+ * retrieval_backend.py:245 + :371-372 (and retrieval_adapter.py:129-131) -- over the
+ * whole docs.jsonl corpus (ingest row order, my_code/ingest_hotpotqa.py:73-81).
+ * Rows are stored in HBM as fp16/bf16 [n, dim padded to 64]; tie-break is
+ * (score desc, row id asc). */
+int mrag_index_create(int dim, int metric, int storage_dtype, int device, mrag_handle* out);
+int mrag_index_destroy(mrag_handle h);
+int mrag_index_reserve(mrag_handle h, int64_t n_rows);
+/* append n rows (row-major [n, dim] of src_dtype).  normalize != 0: L2-normalise each
+ * row (fp64 norm, zero rows stay zero -> cosine 0.0 like :197) before rounding once to
+ * the storage dtype; normalize == 0: rows are rounded/stored as given. */
+int mrag_index_add(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize,
+                   int rows_is_device, void* stream);
+int mrag_index_size(mrag_handle h, int64_t* out_rows);
+int mrag_index_dim(mrag_handle h, int* out_dim);
+/* ids reported by search = id_base + local row (row-sharded corpora) */
+int mrag_index_set_id_base(mrag_handle h, int64_t id_base);
+/* copy stored (rounded) rows [row0, row0+n) back as fp32 [n, dim] -- for tests/caches */
+int mrag_index_get_rows(mrag_handle h, int64_t row0, int64_t n, float* out, int out_is_device, void* stream);
+/* top-k of every query against every stored row.  out_scores [nq,k] fp32 descending,
+ * out_ids [nq,k] int64; slots past the corpus size hold (-inf, -1). */
+int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize,
+                      int queries_is_device, int k, float* out_scores, int64_t* out_ids,
+                      int out_is_device, void* stream);
+/* timing hooks for bench.py: device time in ms of the dominant kernel (fused similarity
+ * GEMM + top-k) and of the whole search of the LAST mrag_index_search call, measured with
+ * hipEvents on the stream the kernels were launched on.  Blocks until that call is done. */
+int mrag_index_last_timing(mrag_handle h, float* out_gemm_ms, float* out_total_ms);
+
+/* ---- 8e: host-side merge of per-shard partial top-k ------------------------------
+ * scores [nparts, nq, k] fp32 and ids [nparts, nq, k] int64 (ids < 0 = empty slot), as
+ * gathered by the RCCL all-gather.  Result ordered by (score desc, id asc). */
+int mrag_topk_merge(const float* scores, const int64_t* ids, int nparts, int64_t nq, int k,
+                    float* out_scores, int64_t* out_ids, int nthreads);
+
+/* ---- IVF-flat (BASELINE.json config 5; no counterpart in the reference) ----------- */
+int mrag_ivf_create(int dim, int nlist, int metric, int storage_dtype, int device, mrag_handle* out);
+int mrag_ivf_destroy(mrag_handle h);
+/* spherical k-means on the device, seeded: init = rows picked by the host from `seed` */
+int mrag_ivf_train(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize,
+                   int rows_is_device, int iters, uint64_t seed, void* stream);
+int mrag_ivf_set_centroids(mrag_handle h, const void* centroids, int src_dtype, int normalize,
+                           int is_device, void* stream);
+int mrag_ivf_get_centroids(mrag_handle h, float* out, int out_is_device, void* stream);
+int mrag_ivf_add(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize,
+                 int rows_is_device, void* stream);
+int mrag_ivf_size(mrag_handle h, int64_t* out_rows);
+int mrag_ivf_set_id_base(mrag_handle h, int64_t id_base);
+/* list id of every stored row, in insertion order */
+int mrag_ivf_get_assignments(mrag_handle h, int32_t* out, int out_is_device, void* stream);
+int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize,
+                    int queries_is_device, int nprobe, int k, float* out_scores, int64_t* out_ids,
+                    int out_is_device, void* stream);
+
+/* ---- a5: sentence-encoder forward, fills the LLMProvider.embed slot ---------------
+ * app/core/providers/base.py:6, called as embed(model=, texts=, require=) from
+ * app/core/llm_router.py:115.  BERT-family encoder (MiniLM-L6 / bge-base shapes,
+ * SURVEY 8c): embeddings + LayerNorm, L x {MHA, erf-GELU FFN, post-LN}, pooling,
+ * optional L2 normalisation.  Tokenisation stays on the host. */
+typedef struct mrag_encoder_config {
+  int32_t vocab_size;
+  int32_t hidden;
+  int32_t layers;
+  int32_t heads;
+  int32_t intermediate;
+  int32_t max_position;
+  int32_t type_vocab_size;
+  float layer_norm_eps;
+  int32_t compute_dtype; /* MRAG_F16 or MRAG_BF16 */
+} mrag_encoder_config;
+
+int mrag_encoder_create(const mrag_encoder_config* cfg, int device, mrag_handle* out);
+int mrag_encoder_destroy(mrag_handle h);
+/* upload one named fp32 parameter (HF BertModel state_dict names, e.g.
+ * "embeddings.word_embeddings.weight", "encoder.layer.3.attention.self.query.bias") */
+int mrag_encoder_set_param(mrag_handle h, const char* name, const float* data, int64_t numel,
+                           int is_device, void* stream);
+/* number of parameters still missing (0 = ready) */
+int mrag_encoder_missing_params(mrag_handle h, int* out_missing);
+/* ids/mask int32 [B,S]; out fp32 [B,hidden] */
+int mrag_encoder_forward(mrag_handle h, const int32_t* ids, const int32_t* mask, int B, int S,
+                         float* out, int pool, int normalize, int io_is_device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRAG_H_ */

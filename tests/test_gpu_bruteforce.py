@@ -1,0 +1,194 @@
+"""GPU parity: fused MFMA cosine top-k (through the C ABI) vs the CPU oracle on identical
+fp16/bf16 input bits.  Integer/index work (ids) is exact outside fp32-accumulation
+near-ties; scores within 1e-5 of the fp64 oracle (north-star tolerance: 1e-3)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import dense_search as ds
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _index(c16, **kw):
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(c16.shape[1], **kw)
+    ix.add(c16, normalize=False)
+    return ix
+
+
+def _check(ix, q16, c16, k, tol=TOL, id_base=0):
+    sc, ids = ix.search(q16, k, normalize=False)
+    rv, ri = ds.brute_force_topk(q16, c16, k)
+    ri = np.where(ri >= 0, ri + id_base, ri)
+    assert sc.shape == (q16.shape[0], k) and ids.dtype == np.int64
+    valid = ri >= 0
+    assert ((ids >= 0) == valid).all()
+    assert np.isneginf(sc[~valid]).all()
+    np.testing.assert_allclose(sc[valid], rv[valid], rtol=0, atol=tol)
+    assert (np.diff(sc, axis=1)[valid[:, 1:]] <= 0).all()            # descending
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=tol)
+    assert bad == 0, (strict, bad)
+    assert ds.recall_at_k(ids, ri) >= 0.999
+    return sc, ids, rv, ri
+
+
+def test_c1_shape_against_reference_golden(golden_dir):
+    """BASELINE config 1 shape (100 x 5000 x 384, k=10) against F5 = the reference's own
+    _cosine over the same rows."""
+    z = np.load(golden_dir / "f5_bruteforce_c1.npz")
+    c16 = ds.normalize_round(ds.make_gaussian(int(z["n"]), int(z["d"]), int(z["corpus_seed"])))
+    q16 = ds.normalize_round(ds.make_gaussian(int(z["nq"]), int(z["d"]), int(z["query_seed"])))
+    assert hashlib.sha256(c16.tobytes()).hexdigest() == str(z["corpus_sha256"])
+    ix = _index(c16)
+    sc, ids, _, _ = _check(ix, q16, c16, int(z["k"]))
+    strict, bad = ds.gap_aware_id_match(ids, sc, z["ids"], z["scores"], tol=1e-3)
+    assert bad == 0 and strict > 500
+    assert ds.recall_at_k(ids, z["ids"]) >= 0.999
+    same = ids == z["ids"]
+    np.testing.assert_allclose(sc[same], z["scores"][same], rtol=0, atol=1e-3)   # cosine within 1e-3
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(3, 5, 8, 10), (1, 1, 64, 1), (7, 255, 40, 4), (64, 257, 96, 10),
+                                      (300, 20000, 768, 10), (33, 4097, 384, 16), (20, 3000, 128, 17),
+                                      (10, 2500, 256, 64)])
+def test_shapes_f16(nq, n, d, k):
+    c16 = ds.normalize_round(ds.make_gaussian(n, d, 1234))
+    q16 = ds.normalize_round(ds.make_gaussian(nq, d, 5678))
+    _check(_index(c16), q16, c16, k)
+
+
+@pytest.mark.parametrize("nq,n", [(600, 20000), (2100, 70000), (257, 131072 + 5)])
+def test_many_query_tiles_xcd_map(nq, n):
+    d, k = 128, 10
+    c16 = ds.normalize_round(ds.make_gaussian(n, d, 11))
+    q16 = ds.normalize_round(ds.make_gaussian(nq, d, 12))
+    _check(_index(c16), q16, c16, k)
+
+
+def test_bf16_storage():
+    import torch
+    n, nq, d, k = 9000, 50, 256, 10
+    c = torch.from_numpy(ds.l2_normalize(ds.make_gaussian(n, d, 1))).to(torch.bfloat16)
+    q = torch.from_numpy(ds.l2_normalize(ds.make_gaussian(nq, d, 2))).to(torch.bfloat16)
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(d, dtype="bf16")
+    ix.add(c, normalize=False)
+    sc, ids = ix.search(q, k, normalize=False)
+    rv, ri = ds.brute_force_topk(q.to(torch.float64).numpy(), c.to(torch.float64).numpy(), k)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=TOL)
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=TOL)
+    assert bad == 0
+
+
+def test_exact_ties_break_by_row():
+    """small-integer rows: every product and partial sum is exact in fp32, so ids must match the
+    (score desc, row asc) order exactly, ties included."""
+    rng = np.random.default_rng(3)
+    c = rng.integers(-2, 3, size=(5000, 64)).astype(np.float16)
+    q = rng.integers(-2, 3, size=(40, 64)).astype(np.float16)
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(64, metric="ip")
+    ix.add(c, normalize=False)
+    for k in (1, 10, 16, 33):
+        sc, ids = ix.search(q, k, normalize=False)
+        rv, ri = ds.brute_force_topk(q, c, k)
+        assert (ids == ri).all()
+        assert (sc == rv.astype(np.float32)).all()
+
+
+def test_all_rows_identical():
+    c = np.tile(ds.normalize_round(ds.make_gaussian(1, 64, 5)), (3000, 1))
+    q = ds.normalize_round(ds.make_gaussian(5, 64, 6))
+    sc, ids = _index(c).search(q, 10, normalize=False)
+    assert (ids == np.arange(10)[None, :]).all()
+
+
+def test_adversarial_increasing_scores_replay_path():
+    """every corpus tile beats the previous one for every query: candidate lists overflow and
+    the kernel replays tiles in sub-rounds with compaction -- results must still be exact."""
+    d, n, nq, k = 64, 6000, 300, 10
+    u = ds.l2_normalize(ds.make_gaussian(1, d, 9))[0]
+    a = np.linspace(0.05, 1.0, n, dtype=np.float32)
+    c = (a[:, None] * u[None, :]).astype(np.float16)
+    q = ds.normalize_round(u[None, :] + 0.01 * ds.make_gaussian(nq, d, 10))
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(d, metric="ip")
+    ix.add(c, normalize=False)
+    sc, ids = ix.search(q, k, normalize=False)
+    rv, ri = ds.brute_force_topk(q, c, k)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=TOL)
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=TOL)
+    assert bad == 0
+    assert ds.recall_at_k(ids, ri) >= 0.999
+
+
+def test_normalize_on_device_matches_oracle_rounding():
+    """K1: fp64 norm, one rounding to fp32, one to fp16 -- same bits as the oracle's
+    normalize_round (allowing 1 fp16 ulp on a vanishing fraction for the fp64 sum order)."""
+    x = ds.make_gaussian(3000, 384, 21)
+    x[17] = 0
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(384)
+    ix.add(x)                       # normalise on the GPU
+    got = ix.rows().astype(np.float16)
+    want = ds.normalize_round(x)
+    diff = got.view(np.uint16).astype(np.int32) - want.view(np.uint16).astype(np.int32)
+    assert (np.abs(diff) <= 1).all() and (diff != 0).mean() < 1e-5
+    assert (got[17] == 0).all()
+    q = ds.make_gaussian(20, 384, 22)
+    sc, ids = ix.search(q, 10)      # normalise queries on the GPU too
+    rv, ri = ds.brute_force_topk(ds.normalize_round(q), want, 10)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-4)
+    assert ds.recall_at_k(ids, ri) >= 0.99
+    sc0, _ = ix.search(np.zeros((1, 384), np.float32), 5)   # zero query -> cosine 0.0, never NaN
+    assert (sc0 == 0).all()
+
+
+def test_incremental_add_id_base_and_device_tensors():
+    import torch
+    d, k = 96, 10
+    c16 = ds.normalize_round(ds.make_gaussian(7001, d, 31))
+    q16 = ds.normalize_round(ds.make_gaussian(129, d, 32))
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(d)
+    for lo in range(0, 7001, 1500):                       # grows + re-allocates
+        ix.add(torch.from_numpy(c16[lo:lo + 1500]).cuda(), normalize=False)
+    assert len(ix) == 7001
+    ix.set_id_base(1_000_000_000_000)
+    _check(ix, q16, c16, k, id_base=1_000_000_000_000)
+    sc_d, ids_d = ix.search(torch.from_numpy(q16).cuda(), k, normalize=False)
+    torch.cuda.synchronize()
+    sc_h, ids_h = ix.search(q16, k, normalize=False)
+    assert (ids_d.cpu().numpy() == ids_h).all() and (sc_d.cpu().numpy() == sc_h).all()
+    g_ms, t_ms = ix.last_timing_ms()
+    assert 0 < g_ms <= t_ms
+
+
+def test_errors_are_loud():
+    from mrag_amd.index import DenseIndex
+    from mrag_amd._native import MragError
+    ix = DenseIndex(32)
+    with pytest.raises(MragError):
+        ix.search(np.zeros((1, 32), np.float32), 65)      # k above the fused limit
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((3, 31), np.float32))
+    sc, ids = ix.search(np.ones((2, 32), np.float32), 3)   # empty index
+    assert (ids == -1).all() and np.isneginf(sc).all()
+
+
+def test_cosine_f64_matches_reference_formula(golden_dir):
+    from mrag_amd.index import cosine_f64
+    from oracle.ref_semantics import cosine
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal(768)
+    c = rng.standard_normal((200, 768))
+    c[3] = 0
+    got = cosine_f64(q, c)
+    want = np.asarray([cosine(list(q), list(v)) for v in c])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
+    assert got[3] == 0.0
+    assert (cosine_f64(np.zeros(768), c) == 0).all()
