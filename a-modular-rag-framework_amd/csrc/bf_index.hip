@@ -39,6 +39,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace mrag {
@@ -59,14 +60,14 @@ constexpr int GEMM_LDS = 2 * STAGE_BYTES;       // 128 KiB
 constexpr int OFF_TAU = GEMM_LDS;               // float[256]
 constexpr int OFF_CNT = OFF_TAU + 1024;         // int[256]
 constexpr int OFF_CNTPRE = OFF_CNT + 1024;      // int[256]
-constexpr int OFF_INIT = OFF_CNTPRE + 1024;     // uint[256]  tile-0 threshold, orderable bits
-constexpr int OFF_FLAGS = OFF_INIT + 1024;      // int[4]
+constexpr int OFF_STAT = OFF_CNTPRE + 1024;     // uint[2][256] threshold certificates, orderable bits
+constexpr int OFF_FLAGS = OFF_STAT + 2048;      // int[4]
 constexpr int LDS_TOTAL = OFF_FLAGS + 16;
 
 constexpr int CAP = 256;   // candidate list capacity per (workgroup, query)
 constexpr int HW = 192;    // compaction high-water mark (CAP - HW >= 64 = max pushes per sub-round)
 constexpr int KMAX = 64;   // largest k the fused filter serves
-constexpr int K_FAST_INIT = 16;
+constexpr int K_CERT = 16;  // k served by the 16-row threshold certificate
 
 struct BfParams {
   const uint16_t* corpus;   // [n_cap][ld]
@@ -75,11 +76,15 @@ struct BfParams {
   int ksteps;               // ld / 64
   int n_rows;               // valid corpus rows
   int n_ctiles;             // ceil(n_rows / 256)
+  int nq;                   // valid queries (rows >= nq of the last query tile are padding)
   int T;                    // query tiles
   int S;                    // corpus splits
   int k;
   int xcd_map;              // 1: S % 8 == 0, use the XCD-aware block -> (t, s) map
-  uint2* lists;             // [T*S][256][CAP]  {score bits, local row}
+  int dbg;                  // development ablations (MRAG_DEBUG_FLAGS); 0 in production
+  long long* stamps;        // dbg & 16: block 0 / wave 0 writes s_memtime stamps here
+  uint32_t* list_sc;        // [T*S][256][CAP]  score bits   (SoA: two dword stores per push, no
+  uint32_t* list_row;       // [T*S][256][CAP]  local row      64-bit store operands to pre-form)
   int* counts;              // [T*S][256]
 };
 
@@ -90,6 +95,13 @@ __device__ __forceinline__ uint32_t f32_ord(float f) {
 __device__ __forceinline__ float ord_f32(uint32_t o) {
   uint32_t b = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
   return __uint_as_float(b);
+}
+// largest float strictly below x in comparison order (x finite or -inf; -inf stays -inf)
+__device__ __forceinline__ float next_below(float x) {
+  if (x == -INFINITY) return x;
+  float nb = ord_f32(f32_ord(x) - 1u);
+  if (nb == x) nb = ord_f32(f32_ord(nb) - 1u);   // +0.0 -> -0.0 compares equal: step once more
+  return nb;
 }
 // larger key = better: higher score first, then LOWER row
 __device__ __forceinline__ uint64_t make_key(uint32_t score_bits, uint32_t row) {
@@ -112,10 +124,20 @@ template <> struct Mfma<MRAG_BF16> {
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-// One wave compacts query q's list to its k best (sorted, best first) and raises tau.
-__device__ __forceinline__ void compact_query(uint2* __restrict__ list, int q, int k, int lane) {
+#define MRAG_STAMP(i)                                                                     \
+  do {                                                                                    \
+    if ((p.dbg & 16) && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {                    \
+      p.stamps[stamp_n * 2] = (i);                                                        \
+      p.stamps[stamp_n * 2 + 1] = (long long)__builtin_readcyclecounter();                \
+      ++stamp_n;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+// One wave compacts query q's list to its k best (sorted, best first) and raises tau_c.
+// Rank by counting over <= CAP entries; rare by construction (see file header).
+__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k, int lane) {
   int* cnt = (int*)(smem + OFF_CNT);
-  float* tau = (float*)(smem + OFF_TAU);
+  float* tau_c = (float*)(smem + OFF_TAU);
   const int c = min(cnt[q], CAP);
   constexpr int R = CAP / 64;
   uint2 ent[R];
@@ -128,7 +150,7 @@ __device__ __forceinline__ void compact_query(uint2* __restrict__ list, int q, i
     key[r] = 0ull;
     rank[r] = 0;
     if (idx < c) {
-      ent[r] = list[idx];
+      ent[r] = make_uint2(lsc[idx], lrow[idx]);
       key[r] = make_key(ent[r].x, ent[r].y);
     }
   }
@@ -147,15 +169,16 @@ __device__ __forceinline__ void compact_query(uint2* __restrict__ list, int q, i
   for (int r = 0; r < R; ++r) {
     const int idx = r * 64 + lane;
     if (idx < c && rank[r] < k) {
-      list[rank[r]] = ent[r];
-      if (rank[r] == k - 1) tau[q] = __uint_as_float(ent[r].x);
+      lsc[rank[r]] = ent[r].x;
+      lrow[rank[r]] = ent[r].y;
+      if (rank[r] == k - 1) tau_c[q] = __uint_as_float(ent[r].x);
     }
   }
   if (lane == 0) cnt[q] = min(c, k);
 }
 
 // Owner wave w (queries 32w .. 32w+31) compacts every list at or above the high-water mark.
-__device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_lists, int w, int lane, int k, bool record_pre) {
+__device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int w, int lane, int k, bool record_pre) {
   int* cnt = (int*)(smem + OFF_CNT);
   int* cnt_pre = (int*)(smem + OFF_CNTPRE);
   const int q = w * 32 + (lane & 31);
@@ -165,17 +188,9 @@ __device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_lists, int 
     const int b = __builtin_ctzll(m);
     m &= m - 1;
     const int qq = w * 32 + b;
-    compact_query(wg_lists + (size_t)qq * CAP, qq, k, lane);
+    compact_query(wg_sc + (size_t)qq * CAP, wg_row + (size_t)qq * CAP, qq, k, lane);
   }
   if (record_pre && lane < 32) cnt_pre[q] = cnt[q];
-}
-
-__device__ __forceinline__ void push_candidate(uint2* __restrict__ wg_lists, int q, float v, int row) {
-  int* cnt = (int*)(smem + OFF_CNT);
-  int* flags = (int*)(smem + OFF_FLAGS);
-  const int slot = atomicAdd(&cnt[q], 1);
-  if (slot < CAP) wg_lists[(size_t)q * CAP + slot] = make_uint2(__float_as_uint(v), (uint32_t)row);
-  else flags[0] = 1;
 }
 
 template <int DT>
@@ -185,6 +200,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
+  int stamp_n = 0;
+  MRAG_STAMP(0);
 
   // ---- block -> (query tile t, corpus split s) ------------------------------------------
   int t, s;
@@ -213,22 +230,24 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     }
   }
   const int wg = t * p.S + s;
-  uint2* wg_lists = p.lists + (size_t)wg * TQ * CAP;
+  uint32_t* wg_sc = p.list_sc + (size_t)wg * TQ * CAP;
+  uint32_t* wg_row = p.list_row + (size_t)wg * TQ * CAP;
   const int tile_lo = (int)(((long long)s * p.n_ctiles) / p.S);
   const int tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
   const int ksteps = p.ksteps;
   const int n_steps = (tile_hi - tile_lo) * ksteps;
 
-  float* tau = (float*)(smem + OFF_TAU);
+  float* tau_c = (float*)(smem + OFF_TAU);
   int* cnt = (int*)(smem + OFF_CNT);
   int* cnt_pre = (int*)(smem + OFF_CNTPRE);
-  uint32_t* init_ord = (uint32_t*)(smem + OFF_INIT);
+  uint32_t* stat = (uint32_t*)(smem + OFF_STAT);   // [2][256] orderable bits, atomicMin target
   int* flags = (int*)(smem + OFF_FLAGS);
   if (tid < TQ) {
-    tau[tid] = -INFINITY;
+    tau_c[tid] = -INFINITY;
     cnt[tid] = 0;
     cnt_pre[tid] = 0;
-    init_ord[tid] = 0xFFFFFFFFu;
+    stat[tid] = 0xFFFFFFFFu;
+    stat[TQ + tid] = 0xFFFFFFFFu;
   }
   if (tid == 0) flags[0] = 0;
 
@@ -272,9 +291,14 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // running two largest per-tile maxima of this lane, per query column (k <= 16 certificate)
+  float rm1[4], rm2[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) rm1[nf] = rm2[nf] = -INFINITY;
 
   if (n_steps > 0) stage(0, 0);
   __syncthreads();
+  MRAG_STAMP(1);
 
   for (int step = 0; step < n_steps; ++step) {
     const int buf = step & 1;
@@ -296,18 +320,30 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     }
 
     const int kk = step % ksteps;
-    if (kk == ksteps - 1) {
+    if (kk == ksteps - 1 && (p.dbg & 1)) {
+      // ablation: no top-k filter; keep the accumulators observable, then clear them
+      float x = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          x += acc[mf][nf][0] + acc[mf][nf][1] + acc[mf][nf][2] + acc[mf][nf][3];
+          acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      if (x == 123456.789f) cnt[0] = 1;
+    } else if (kk == ksteps - 1) {
       // =========================== fused top-k epilogue ===================================
       const int ti = step / ksteps;  // tile index inside the split
       const int tile = tile_lo + ti;
       // lane-derived values are recomputed from an opaque copy so that nothing the epilogue
-      // needs is hoisted out of the K loop (the loop body is at the 256-VGPR budget)
+      // needs is hoisted out of the K loop (the loop body is near the 256-VGPR budget)
       int elane = lane;
       asm volatile("" : "+v"(elane));
       const int row0 = tile * TM + wm * 128 + (elane >> 4) * 4;  // + mf*16 + j
       const int q0 = wn * 64 + (elane & 15);                     // + nf*16
-      const bool partial = (tile + 1) * TM > p.n_rows;
-      if (partial) {
+      const bool certify = p.k <= K_CERT;
+      MRAG_STAMP(10 + (ti == 0 ? 0 : 100));
+      if ((tile + 1) * TM > p.n_rows) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -317,10 +353,24 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
               for (int nf = 0; nf < 4; ++nf) acc[mf][nf][j] = -INFINITY;
             }
       }
+      // per-lane maximum of the tile, per query column
+      float tmax[4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        float m = acc[0][nf][0];
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m = fmaxf(m, acc[mf][nf][j]);
+        tmax[nf] = m;
+      }
       float thr[4];
+      uint32_t* stat_cur = stat + (ti & 1) * TQ;        // certificate built from tiles <= ti
+      uint32_t* stat_prev = stat + ((ti & 1) ^ 1) * TQ;  // certificate from tiles < ti
       if (ti == 0) {
-        // ---- first tile: seed the thresholds, push with '>=' ------------------------------
-        if (p.k <= K_FAST_INIT) {
+        // ---- first tile: tau0 = min over the query's 8 lane groups of the group's 2nd largest
+        // score IN this tile; >= 16 rows are >= tau0, so pass on '>=' (as '> next_below').
+        if (certify) {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {
             float m1 = -INFINITY, m2 = -INFINITY;
@@ -332,84 +382,121 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
                 m2 = fmaxf(m2, fminf(m1, v));
                 m1 = fmaxf(m1, v);
               }
+            rm1[nf] = m1;
+            rm2[nf] = m2;
             float x = m2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
-            if (elane < 16) atomicMin(&init_ord[q0 + nf * 16], f32_ord(x));
+            if (elane < 16) atomicMin(&stat_cur[q0 + nf * 16], f32_ord(x));
           }
           __syncthreads();
+          MRAG_STAMP(11);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = ord_f32(init_ord[q0 + nf * 16]);
+          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
         } else {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) thr[nf] = -INFINITY;
         }
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-          for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float v = acc[mf][nf][j];
-              const int row = row0 + mf * 16 + j;
-              if (v >= thr[nf] && row < p.n_rows) push_candidate(wg_lists, q0 + nf * 16, v, row);
-            }
-        // >= 16 >= k listed entries are >= tau0 and come from earlier rows than any later tile
-        if (wm == 0 && elane < 16) {
-#pragma unroll
-          for (int nf = 0; nf < 4; ++nf) tau[q0 + nf * 16] = thr[nf];
-        }
       } else {
-        // ---- later tiles: wave-uniform skip unless some score beats its threshold ---------
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) thr[nf] = tau[q0 + nf * 16];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          float m = acc[0][nf][0];
+          const float sc = certify ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
+          thr[nf] = fmaxf(sc, tau_c[q0 + nf * 16]);
+        }
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        if (t * TQ + q0 + nf * 16 >= p.nq) thr[nf] = INFINITY;   // padding queries never list anything
+
+      // ---- push: attempt 0 = whole tile at once; on list overflow replay in 4 sub-rounds ------
+      int attempt = 0, round = 0;
+      while (true) {
+        const uint32_t srmask = attempt ? (0xFFu << (8 * round)) : 0xFFFFFFFFu;
+        int rbase = row0;
+        asm volatile("" : "+v"(rbase));   // keep the 128 {score,row} store operands from being pre-formed (and spilled) outside this loop
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          if (!__any(tmax[nf] > thr[nf])) continue;
+          uint32_t mask = 0;
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m = fmaxf(m, acc[mf][nf][j]);
-          if (__any(m > thr[nf])) {
-#pragma unroll
-            for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float v = acc[mf][nf][j];
-                if (v > thr[nf]) push_candidate(wg_lists, q0 + nf * 16, v, row0 + mf * 16 + j);
-              }
+            for (int j = 0; j < 4; ++j) mask |= (acc[mf][nf][j] > thr[nf]) ? (1u << (mf * 4 + j)) : 0u;
+          mask &= srmask;
+          const int q = q0 + nf * 16;
+          const int n_new = __popc(mask);
+          int base = 0;
+          if (n_new) {
+            base = atomicAdd(&cnt[q], n_new);
+            if (base + n_new > CAP) flags[0] = 1;
           }
-        }
-      }
-      __syncthreads();
-      if (flags[0]) {
-        // ---- overflow: replay this tile in 4 sub-rounds (<= 64 pushes per query each) ------
-        __syncthreads();
-        if (tid < TQ) cnt[tid] = cnt_pre[tid];
-        if (tid == 0) flags[0] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int sr = 0; sr < 4; ++sr) {
-#pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = tau[q0 + nf * 16];
+          uint32_t* lsc = wg_sc + (size_t)q * CAP;
+          uint32_t* lrow = wg_row + (size_t)q * CAP;
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf) {
-            if ((mf >> 1) != sr) continue;
+            if (!__any((mask >> (mf * 4)) & 0xFu)) continue;
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float v = acc[mf][nf][j];
-                if (v > thr[nf]) push_candidate(wg_lists, q0 + nf * 16, v, row0 + mf * 16 + j);
+            for (int j = 0; j < 4; ++j) {
+              const int bit = mf * 4 + j;
+              if (mask & (1u << bit)) {
+                const int slot = base + __popc(mask & ((1u << bit) - 1u));
+                if (slot < CAP) {
+                  lsc[slot] = __float_as_uint(acc[mf][nf][j]);
+                  lrow[slot] = (uint32_t)(rbase + mf * 16 + j);
+                }
               }
+            }
           }
-          __syncthreads();
-          compact_owned(wg_lists, w, elane, p.k, sr == 3);
-          __syncthreads();
         }
-      } else {
-        compact_owned(wg_lists, w, elane, p.k, true);
+        if (attempt == 0 && certify) {
+          // fold this tile's maxima into the running certificate used from the NEXT tile on
+          if (ti != 0) {
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+              rm2[nf] = fmaxf(rm2[nf], fminf(rm1[nf], tmax[nf]));
+              rm1[nf] = fmaxf(rm1[nf], tmax[nf]);
+              float x = rm2[nf];
+              x = fminf(x, __shfl_xor(x, 16));
+              x = fminf(x, __shfl_xor(x, 32));
+              if (elane < 16) atomicMin(&stat_cur[q0 + nf * 16], f32_ord(x));
+            }
+          }
+        }
+        MRAG_STAMP(12 + (ti == 0 ? 0 : 100));
+        __syncthreads();
+        MRAG_STAMP(13 + (ti == 0 ? 0 : 100));
+        if (attempt == 0) {
+          if (!flags[0]) {
+            compact_owned(wg_sc, wg_row, w, elane, p.k, true);
+            if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;   // becomes stat_cur of tile ti+1
+            break;
+          }
+          __syncthreads();               // everyone has seen the flag
+          if (tid < TQ) cnt[tid] = cnt_pre[tid];
+          if (tid == 0) flags[0] = 0;
+          __syncthreads();
+          attempt = 1;
+          round = 0;
+        } else {
+          compact_owned(wg_sc, wg_row, w, elane, p.k, round == 3);
+          __syncthreads();
+          if (round == 3) {
+            if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;
+            break;
+          }
+          ++round;
+        }
+        if (attempt) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            const float sc = (certify && ti != 0) ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
+            float th = fmaxf(sc, tau_c[q0 + nf * 16]);
+            if (t * TQ + q0 + nf * 16 >= p.nq) th = INFINITY;
+            thr[nf] = fmaxf(thr[nf], th);
+          }
+        }
       }
+      MRAG_STAMP(14 + (ti == 0 ? 0 : 100));
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
@@ -419,6 +506,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   }
 
   __syncthreads();
+  MRAG_STAMP(99);
   if (tid < TQ) p.counts[(size_t)wg * TQ + tid] = min(cnt[tid], CAP);
 }
 
@@ -428,7 +516,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 constexpr int MERGE_LDS_ENT = 4096;
 
 struct MergeParams {
-  const uint2* lists;
+  const uint32_t* list_sc;
+  const uint32_t* list_row;
   const int* counts;
   int T, S, k;
   int64_t nq;
@@ -466,11 +555,11 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
     while (s < p.S) {
       const int wg = t * p.S + s;
       const int c = p.counts[(size_t)wg * TQ + ql];
-      const uint2* l = p.lists + ((size_t)wg * TQ + ql) * CAP;
+      const uint32_t* lsc = p.list_sc + ((size_t)wg * TQ + ql) * CAP;
+      const uint32_t* lrow = p.list_row + ((size_t)wg * TQ + ql) * CAP;
       const int take = min(c - pos, MERGE_LDS_ENT - fill);
       for (int i = lane; i < take; i += 64) {
-        const uint2 e = l[pos + i];
-        keys[fill + i] = make_key(e.x, e.y);
+        keys[fill + i] = make_key(lsc[pos + i], lrow[pos + i]);
       }
       fill += take;
       pos += take;
@@ -540,6 +629,8 @@ struct BfIndex : Object {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
   }
 };
+
+static long long* g_stamps = nullptr;  // diagnostic s_memtime stamps (MRAG_DEBUG_FLAGS & 16)
 
 static size_t dtype_size(int dt) {
   switch (dt) { case MRAG_F32: return 4; case MRAG_F16: case MRAG_BF16: return 2; case MRAG_F64: return 8; default: return 0; }
@@ -740,7 +831,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
     MRAG_TRY(launch_prep_rows(qsrc, q_dtype, nq, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                               normalize && ix->metric == MRAG_METRIC_COSINE, stream));
-    MRAG_TRY(ix->lists.ensure(grid * TQ * CAP * sizeof(uint2)));
+    MRAG_TRY(ix->lists.ensure(grid * TQ * CAP * 8));
     MRAG_TRY(ix->counts.ensure(grid * TQ * sizeof(int)));
 
     BfParams p;
@@ -750,11 +841,24 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     p.ksteps = ix->ld / BK;
     p.n_rows = (int)ix->n;
     p.n_ctiles = n_ctiles;
+    p.nq = (int)nq;
     p.T = T;
     p.S = S;
     p.k = k;
     p.xcd_map = xcd;
-    p.lists = (uint2*)ix->lists.p;
+    {
+      static int dbg = -1;
+      if (dbg < 0) { const char* e = getenv("MRAG_DEBUG_FLAGS"); dbg = e ? atoi(e) : 0; }
+      p.dbg = dbg;
+    }
+    p.stamps = nullptr;
+    if (p.dbg & 16) {
+      if (!g_stamps) MRAG_HIP(hipMalloc((void**)&g_stamps, 128 * 8));
+      MRAG_HIP(hipMemsetAsync(g_stamps, 0, 128 * 8, stream));
+      p.stamps = g_stamps;
+    }
+    p.list_sc = (uint32_t*)ix->lists.p;
+    p.list_row = p.list_sc + grid * TQ * CAP;
     p.counts = (int*)ix->counts.p;
     static bool attr_done[2] = {false, false};
     if (ix->dtype == MRAG_F16) {
@@ -770,7 +874,8 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     MRAG_HIP(hipEventRecord(ix->ev[2], stream));
 
     MergeParams mp;
-    mp.lists = p.lists;
+    mp.list_sc = p.list_sc;
+    mp.list_row = p.list_row;
     mp.counts = p.counts;
     mp.T = T; mp.S = S; mp.k = k;
     mp.nq = nq;
@@ -782,6 +887,15 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
   }
   MRAG_HIP(hipEventRecord(ix->ev[3], stream));
   ix->timed = true;
+  if (g_stamps && ix->n > 0) {   // diagnostic build path only (MRAG_DEBUG_FLAGS & 16)
+    long long hs[128];
+    MRAG_HIP(hipStreamSynchronize(stream));
+    MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[mrag stamps]");
+    for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i)
+      fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
+    fprintf(stderr, "\n");
+  }
   if (!out_is_device) {
     MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
