@@ -87,6 +87,13 @@ def load():
         raise MragLibraryMissing(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C a-modular-rag-framework_amd/csrc`).  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.  Two HIP runtimes
+    # in one process cannot both open the GPU, so torch's copy must be the one already mapped when
+    # libmrag_hip.so resolves its libamdhip64.so.7 dependency (same SONAME -> shared, one runtime).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(p))
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = ABI drift, surface it

@@ -1,0 +1,96 @@
+"""Row-sharded corpus search: one process per GPU, each rank owns a
+contiguous block of corpus rows, runs the fused similarity + top-k locally, then ONE
+all-gather of the per-shard (score, global id) partial top-k (RCCL over xGMI when the
+process group is ``nccl``; ``gloo`` in the CPU tests) followed by the host-side merge
+(``mrag_topk_merge``, C++ threads).  Result = the single-GPU result: ids are global,
+tie-break (score desc, id asc).
+
+The exchange is latency-bound: Q*k*(4+8) bytes per rank (C4: 10 000 x 10 -> 1.2 MB), so a
+direct all-gather on the fully connected xGMI mesh, no ring tuning, no all-reduce.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from .index import topk_merge
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block of ``rank``: [lo, hi)."""
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, bufs: Optional[dict] = None
+                     ) -> Tuple[np.ndarray, np.ndarray]:
+    """All-gather the per-shard partial top-k and merge on the host.
+
+    ``local_scores`` [Q,k] float32 and ``local_ids`` [Q,k] int64 are torch tensors on the
+    backend's device (CUDA for nccl, CPU for gloo).  Every rank returns the full merged
+    (scores [Q,k] float32, ids [Q,k] int64) as numpy arrays.  ``bufs`` (a dict the caller
+    keeps) caches the gather / pinned staging buffers across calls."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    q, k = local_scores.shape
+    if world == 1:
+        return (local_scores.detach().cpu().numpy().astype(np.float32, copy=False),
+                local_ids.detach().cpu().numpy().astype(np.int64, copy=False))
+    bufs = bufs if bufs is not None else {}
+    key = (world, q, k, str(local_scores.device))
+    if bufs.get("key") != key:
+        bufs.clear()
+        bufs["key"] = key
+        bufs["gs"] = torch.empty((world, q, k), dtype=torch.float32, device=local_scores.device)
+        bufs["gi"] = torch.empty((world, q, k), dtype=torch.int64, device=local_ids.device)
+        if local_scores.is_cuda:
+            bufs["hs"] = torch.empty((world, q, k), dtype=torch.float32, pin_memory=True)
+            bufs["hi"] = torch.empty((world, q, k), dtype=torch.int64, pin_memory=True)
+    gs, gi = bufs["gs"], bufs["gi"]
+    dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
+    dist.all_gather_into_tensor(gi, local_ids.contiguous(), group=group)
+    if gs.is_cuda:
+        hs, hi = bufs["hs"], bufs["hi"]
+        hs.copy_(gs, non_blocking=True)
+        hi.copy_(gi, non_blocking=True)
+        torch.cuda.current_stream(gs.device).synchronize()
+        return topk_merge(hs.numpy(), hi.numpy(), nthreads)
+    return topk_merge(gs.numpy(), gi.numpy(), nthreads)
+
+
+class ShardedDenseIndex:
+    """One rank's view of a row-sharded corpus.
+
+    ``local_search(queries, k) -> (scores, ids)`` defaults to a :class:`DenseIndex` on this
+    rank's GPU with ``id_base`` = the shard's first global row; tests inject a CPU searcher
+    to exercise the exchange + merge on ``gloo``."""
+
+    def __init__(self, dim: int, n_total: int, rank: int, world: int, device: int = 0, group=None,
+                 dtype: str = "f16", metric: str = "cosine",
+                 local_search: Optional[Callable] = None):
+        self.dim, self.n_total, self.rank, self.world, self.group = dim, n_total, rank, world, group
+        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self._bufs: dict = {}
+        self.index = None
+        if local_search is None:
+            from .index import DenseIndex
+            self.index = DenseIndex(dim, metric=metric, dtype=dtype, device=device)
+            self.index.set_id_base(self.lo)
+            self.index.reserve(self.hi - self.lo)
+            local_search = self.index.search
+        self._local_search = local_search
+
+    def add_local(self, rows, normalize=None):
+        """Append rows of THIS shard (global rows lo + len(index) ...)."""
+        self.index.add(rows, normalize=normalize)
+        if len(self.index) > self.hi - self.lo:
+            raise ValueError("more rows than this shard owns")
+
+    def search(self, queries, k: int, nthreads: int = 0, **kw) -> Tuple[np.ndarray, np.ndarray]:
+        sc, ids = self._local_search(queries, k, **kw)
+        import torch
+        if not torch.is_tensor(sc):
+            sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
+        return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs)

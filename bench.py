@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of brute-force cosine top-10 over the 1M x 768 fp16 corpus
+(BASELINE.json metric; workload = config C4: a 10 000-query batch, corpus row-sharded over the
+N GPUs of one node, one RCCL all-gather of the per-shard partial top-k + host merge).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one query batch: K1 (normalise + fp16 round of the
+batch) -> K2 (fused MFMA similarity + top-k over this rank's rows) -> K4 (candidate merge) ->
+[N>1: all-gather + ] results on the host.  Corpus and query batch are resident in HBM before
+the timed region.  Total work is fixed as N grows ("scaling": "strong").
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (K2): algorithmic FLOP = 2*Q*N_local*D per launch over the
+                kernel's hipEvent time measured inside the library on the launch stream
+  cpu_baseline  N=1 only: the numpy restatement (oracle.dense_search.brute_force_topk_f32:
+                sgemm + top-k on the same fp16-rounded rows) timed on this host's cores on a
+                bounded query sample over the full corpus
+  recall_at_10  N=1 only: GPU ids vs the fp64 oracle on a query subsample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_CORPUS = 1_000_000
+DIM = 768
+N_QUERIES = 10_000
+TOP_K = 10
+CHUNK = 65536            # data is generated per 65536-row chunk, seed 1234 + chunk: same corpus for every N
+PEAK_TFLOPS_F16 = 2500.0  # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gen_chunk(c: int, dim: int, device):
+    import torch
+    g = torch.Generator(device=device).manual_seed(1234 + c)
+    return torch.randn(CHUNK, dim, device=device, generator=g, dtype=torch.float32)
+
+
+def build_shard(ix, lo: int, hi: int, dim: int, device):
+    c = lo // CHUNK
+    while c * CHUNK < hi:
+        rows = gen_chunk(c, dim, device)
+        a, b = max(lo, c * CHUNK), min(hi, (c + 1) * CHUNK)
+        ix.add(rows[a - c * CHUNK:b - c * CHUNK])
+        c += 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-corpus", type=int, default=N_CORPUS)
+    ap.add_argument("--n-queries", type=int, default=N_QUERIES)
+    ap.add_argument("--dim", type=int, default=DIM)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no CUDA/HIP device visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from mrag_amd.sharded import ShardedDenseIndex, shard_bounds
+
+    n, nq, d, k = args.n_corpus, args.n_queries, args.dim, TOP_K
+    sh = ShardedDenseIndex(d, n, rank, world, device=local_rank)
+    build_shard(sh.index, sh.lo, sh.hi, d, device)
+    gq = torch.Generator(device=device).manual_seed(5678)
+    queries = torch.randn(nq, d, device=device, generator=gq, dtype=torch.float32)
+    torch.cuda.synchronize()
+
+    def step():
+        return sh.search(queries, k)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    gemm_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc, ids = step()
+        gemm_ms.append(sh.index.last_timing_ms()[0])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        n_local = sh.hi - sh.lo
+        k2_ms = float(np.mean(gemm_ms))
+        flop = 2.0 * nq * n_local * d
+        achieved = flop / (k2_ms * 1e-3) / 1e12
+        out = {
+            "metric": "queries/sec (brute-force cosine top-10 over the 1M x 768 fp16 corpus)",
+            "value": nq * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "C4: 10k-query batch x 1M x 768 fp16 corpus, k=10, corpus row-sharded across GPUs, "
+                                   "all-gather partial top-k + host merge",
+                       "n_queries": nq, "n_corpus": n, "dim": d, "k": k,
+                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS_F16, "traffic": None,
+                         "kernel": "bf_gemm_topk_kernel", "kernel_ms": k2_ms, "flop_per_launch": flop},
+            "cpu_baseline": None,
+            "recall_at_10": None,
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import dense_search as ods
+            c32 = sh.index.rows()                                  # the stored fp16 bits, as fp32
+            q16 = ods.normalize_round(queries.cpu().numpy())       # same arithmetic as K1
+            # recall / parity vs the fp64 oracle on a subsample
+            sub = np.arange(0, nq, max(1, nq // 32))[:32]
+            rv, ri = ods.brute_force_topk(q16[sub], c32, k, block=131072)
+            rec = ods.recall_at_k(ids[sub], ri)
+            out["recall_at_10"] = rec
+            out["max_abs_score_err"] = float(np.max(np.abs(sc[sub] - rv)))
+            # CPU baseline: bounded sample, ~10 s of sgemm + top-k over the FULL corpus
+            threads = torch.get_num_threads()
+            q32 = q16.astype(np.float32)
+            t1 = time.perf_counter(); ods.brute_force_topk_f32(q32[:16], c32, k); probe = time.perf_counter() - t1
+            ns = int(min(1024, max(16, 10.0 / max(probe / 16, 1e-6))))
+            t1 = time.perf_counter(); ods.brute_force_topk_f32(q32[:ns], c32, k); cpu_s = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "queries/s", "cores": os.cpu_count(),
+                                   "kind": "port", "blas_threads": threads,
+                                   "sample": f"{ns} of the {nq} queries against the full {n} x {d} corpus "
+                                             f"(numpy sgemm + argpartition top-{k}, {cpu_s:.1f} s)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -205,3 +205,23 @@ def ivf_search(q: np.ndarray, c: np.ndarray, centroids: np.ndarray, assign: np.n
         out_v[i, :len(o)] = s[o]
         out_i[i, :len(o)] = rows[o]
     return out_v, out_i
+
+
+# ------------------------------------------------------------------ CPU baseline ("port")
+def brute_force_topk_f32(q32: np.ndarray, c32: np.ndarray, k: int, block: int = 131072
+                         ) -> Tuple[np.ndarray, np.ndarray]:
+    """The restated CPU path timed as ``cpu_baseline``: fp32 BLAS
+    ``Q @ C.T`` on pre-normalised rows, argpartition + exact ordering of the survivors
+    (score desc, row asc).  Multi-threaded through numpy's BLAS."""
+    nq = q32.shape[0]
+    best_v = np.full((nq, 0), -np.inf, dtype=np.float32)
+    best_i = np.zeros((nq, 0), dtype=np.int64)
+    for lo in range(0, c32.shape[0], block):
+        s = q32 @ c32[lo:lo + block].T
+        kk = min(k, s.shape[1])
+        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+        v = np.concatenate([best_v, np.take_along_axis(s, part, axis=1)], axis=1)
+        i = np.concatenate([best_i, part.astype(np.int64) + lo], axis=1)
+        order = np.lexsort((i, -v), axis=1)[:, :k]
+        best_v, best_i = np.take_along_axis(v, order, axis=1), np.take_along_axis(i, order, axis=1)
+    return best_v, best_i
