@@ -25,17 +25,22 @@
 //   (32 CUs) sharing: 8 query tiles stay in that XCD's L2 (3 MiB at d=768), every corpus
 //   tile is fetched from HBM once per 8 query tiles.
 //
-// Top-k filter (exact):
-//   per query a threshold tau = a lower bound of its current k-th best; a score enters the
-//   query's candidate list only if it beats tau.  First tile of a split: tau0 = min over
-//   the 8 (lane, wave) groups that share the query of the group's 2nd-largest score, so at
-//   least 16 >= k candidates pass (k <= 16; larger k start from -inf).  Later tiles: strict
-//   '>' -- a later row that only ties tau loses the (score desc, row asc) tie-break to the
-//   rows already listed.  Lists hold CAP = 256 entries; at HW = 192 a wave compacts the list
-//   to its k best (rank by counting) and raises tau to the k-th.  Random data: ~16 ln(n/256)
-//   entries per (query, split), compaction is rare.  Adversarial data (every tile beats the
-//   last): the tile is replayed in 4 sub-rounds of <= 64 pushes per query with a compaction
-//   between them -- slower, never wrong.
+// Top-k filter (exact)
+//   Per query a threshold thr certified by ">= k EARLIER rows score >= thr"; a score is listed
+//   only if it beats thr (strict: a later row that ties loses the (score desc, row asc)
+//   tie-break).  Certificates: (a) k <= 16: every lane tracks the two largest per-tile maxima it
+//   has seen for each of its 4 query columns; the minimum over the 8 lanes that share a query
+//   (2 waves x 4 lane groups) of their 2nd-largest is a score that >= 16 earlier rows reach
+//   (LDS ds_min, double-buffered per tile); the first tile bootstraps from its own scores and
+//   passes on '>='.  (b) any k: the k-th best of a compacted list.
+//   Lists: each of the 8 lanes that share a query owns a private 32-entry segment of the
+//   query's list (count kept in a register during the push, committed to LDS after the tile's
+//   barrier): a push is a compare and two predicated stores, no atomics, no waits.
+//   A full segment raises a flag: the tile is replayed in 4 sub-rounds (<= 8 pushes per
+//   segment each) with the affected queries compacted in between -- rank by counting over the
+//   <= 320 listed entries into a 64-entry "kept" area, segments emptied, thr raised to the k-th.
+//   Adversarial inputs (every tile beats the last) take the replay path every tile: slower,
+//   never wrong.
 #include "common.h"
 
 #include <math.h>
@@ -57,17 +62,23 @@ constexpr int NTHR = 512;
 constexpr int A_BYTES = TM * BK * 2;            // 32 KiB
 constexpr int STAGE_BYTES = (TM + TQ) * BK * 2; // 64 KiB
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;       // 128 KiB
-constexpr int OFF_TAU = GEMM_LDS;               // float[256]
-constexpr int OFF_CNT = OFF_TAU + 1024;         // int[256]
-constexpr int OFF_CNTPRE = OFF_CNT + 1024;      // int[256]
-constexpr int OFF_STAT = OFF_CNTPRE + 1024;     // uint[2][256] threshold certificates, orderable bits
-constexpr int OFF_FLAGS = OFF_STAT + 2048;      // int[4]
-constexpr int LDS_TOTAL = OFF_FLAGS + 16;
 
-constexpr int CAP = 256;   // candidate list capacity per (workgroup, query)
-constexpr int HW = 192;    // compaction high-water mark (CAP - HW >= 64 = max pushes per sub-round)
-constexpr int KMAX = 64;   // largest k the fused filter serves
-constexpr int K_CERT = 16;  // k served by the 16-row threshold certificate
+constexpr int NGRP = 8;                   // lanes (2 waves x 4 lane groups) that share a query
+constexpr int SEG = 64;                   // private list segment per (query, lane group)
+constexpr int KEPT = 64;                  // compacted entries per query (= largest k)
+constexpr int QCAP = KEPT + NGRP * SEG;   // 576 list entries per (workgroup, query)
+constexpr int NCNT = 1 + NGRP;            // counters per query: kept + 8 segments
+constexpr int KMAX = KEPT;
+constexpr int K_CERT = 16;                // k served by the 16-row threshold certificate
+
+constexpr int OFF_TAU = GEMM_LDS;               // float[256]      k-th best after a compaction
+constexpr int OFF_KCNT = OFF_TAU + 1024;        // int[256]        kept entries
+constexpr int OFF_SCNT = OFF_KCNT + 1024;       // int[256][8]     committed segment counts
+constexpr int OFF_STAT = OFF_SCNT + 8192;       // uint[2][256]    certificates, orderable bits
+constexpr int OFF_FLAGS = OFF_STAT + 2048;      // int[4]
+constexpr int OFF_RM = OFF_FLAGS + 16;          // float[4 columns][2][512 threads]: each lane's two largest
+                                                // per-tile maxima per query column (kept out of the VGPR budget)
+constexpr int LDS_TOTAL = OFF_RM + 4 * 2 * NTHR * 4;
 
 struct BfParams {
   const uint16_t* corpus;   // [n_cap][ld]
@@ -83,9 +94,9 @@ struct BfParams {
   int xcd_map;              // 1: S % 8 == 0, use the XCD-aware block -> (t, s) map
   int dbg;                  // development ablations (MRAG_DEBUG_FLAGS); 0 in production
   long long* stamps;        // dbg & 16: block 0 / wave 0 writes s_memtime stamps here
-  uint32_t* list_sc;        // [T*S][256][CAP]  score bits   (SoA: two dword stores per push, no
-  uint32_t* list_row;       // [T*S][256][CAP]  local row      64-bit store operands to pre-form)
-  int* counts;              // [T*S][256]
+  uint32_t* list_sc;        // [T*S][256][QCAP]  score bits   (SoA: two dword stores per push)
+  uint32_t* list_row;       // [T*S][256][QCAP]  local row
+  int* counts;              // [T*S][256][NCNT]
 };
 
 __device__ __forceinline__ uint32_t f32_ord(float f) {
@@ -124,6 +135,29 @@ template <> struct Mfma<MRAG_BF16> {
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// LDS accesses of the epilogue's hot path go through inline asm: with LDS-DMA prefetches in
+// flight hipcc guards every ordinary LDS access with s_waitcnt vmcnt(0) (it cannot prove the
+// DMA writes a different LDS region), which would drain the next stage's prefetch -- and every
+// outstanding list store -- once per access.  These wait on lgkmcnt only.
+__device__ __forceinline__ uint32_t lds_off(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ uint32_t lds_load_u32(const void* p) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(p)) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_min_u32(void* p, uint32_t x) {
+  asm volatile("ds_min_u32 %0, %1" : : "v"(lds_off(p)), "v"(x) : "memory");
+}
+__device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"(lds_off(p)), "v"(x) : "memory");
+}
+
+// Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG build (make DIAG=1);
+// the production kernel carries none of them.
+#ifdef MRAG_DIAG
+#define MRAG_DBG(bit) (p.dbg & (bit))
 #define MRAG_STAMP(i)                                                                     \
   do {                                                                                    \
     if ((p.dbg & 16) && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {                    \
@@ -132,65 +166,71 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
       ++stamp_n;                                                                          \
     }                                                                                     \
   } while (0)
+#else
+#define MRAG_DBG(bit) 0
+#define MRAG_STAMP(i) do { } while (0)
+#endif
 
-// One wave compacts query q's list to its k best (sorted, best first) and raises tau_c.
-// Rank by counting over <= CAP entries; rare by construction (see file header).
-__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k, int lane) {
-  int* cnt = (int*)(smem + OFF_CNT);
+// One wave compacts query q: the k best of its kept area + 8 segments go (sorted, best first)
+// into the kept area, the segments are emptied, tau_c rises to the k-th.  The keys are staged
+// through `scratch` (>= QCAP u64 of LDS: the stage buffer the K loop has just consumed), then
+// ranked by counting with broadcast LDS reads.  Register-light on purpose (it shares the
+// kernel's 256-VGPR budget with the 128 accumulators); slow, and rare by construction.
+__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k,
+                                              int lane, uint64_t* __restrict__ scratch) {
   float* tau_c = (float*)(smem + OFF_TAU);
-  const int c = min(cnt[q], CAP);
-  constexpr int R = CAP / 64;
-  uint2 ent[R];
-  uint64_t key[R];
-  int rank[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
+  int* kcnt = (int*)(smem + OFF_KCNT);
+  int* scnt = (int*)(smem + OFF_SCNT);
+  const int kc = kcnt[q];
+  int total = 0;
+#pragma unroll 1
+  for (int r = 0; r < QCAP / 64; ++r) {
     const int idx = r * 64 + lane;
-    ent[r] = make_uint2(0u, 0u);
-    key[r] = 0ull;
-    rank[r] = 0;
-    if (idx < c) {
-      ent[r] = make_uint2(lsc[idx], lrow[idx]);
-      key[r] = make_key(ent[r].x, ent[r].y);
+    bool valid;
+    if (idx < KEPT) valid = idx < kc;
+    else valid = ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
+    uint64_t key = 0ull;
+    if (valid) key = make_key(lsc[idx], lrow[idx]);   // never 0 for a valid entry (row < 2^31)
+    const unsigned long long bal = __ballot(valid);
+    if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    total += __popcll(bal);
+  }
+  // (one wave: program order + the LDS queue order make the staged keys visible to every lane)
+#pragma unroll 1
+  for (int base = 0; base < total; base += 64) {
+    const int i = base + lane;
+    const uint64_t my = i < total ? scratch[i] : ~0ull;
+    int rank = 0;
+#pragma unroll 4
+    for (int j = 0; j < total; ++j) rank += (scratch[j] > my) ? 1 : 0;
+    if (i < total && rank < k) {
+      const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
+      lsc[rank] = sb;
+      lrow[rank] = 0xFFFFFFFFu - (uint32_t)my;
+      if (rank == k - 1) tau_c[q] = __uint_as_float(sb);
     }
   }
-#pragma unroll
-  for (int r2 = 0; r2 < R; ++r2) {
-    const int lim = min(64, c - r2 * 64);
-    const uint32_t khi = (uint32_t)(key[r2] >> 32), klo = (uint32_t)key[r2];
-    for (int jj = 0; jj < lim; ++jj) {
-      const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, jj) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)klo, jj);
-#pragma unroll
-      for (int r = 0; r < R; ++r) rank[r] += (kj > key[r]) ? 1 : 0;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int idx = r * 64 + lane;
-    if (idx < c && rank[r] < k) {
-      lsc[rank[r]] = ent[r].x;
-      lrow[rank[r]] = ent[r].y;
-      if (rank[r] == k - 1) tau_c[q] = __uint_as_float(ent[r].x);
-    }
-  }
-  if (lane == 0) cnt[q] = min(c, k);
+  if (lane == 0) kcnt[q] = min(total, k);
+  if (lane < NGRP) scnt[q * NGRP + lane] = 0;
 }
 
-// Owner wave w (queries 32w .. 32w+31) compacts every list at or above the high-water mark.
-__device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int w, int lane, int k, bool record_pre) {
-  int* cnt = (int*)(smem + OFF_CNT);
-  int* cnt_pre = (int*)(smem + OFF_CNTPRE);
+// Owner wave w (queries 32w .. 32w+31) compacts every query that has a segment above `limit`.
+__device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int w, int lane, int k, int limit,
+                                              uint64_t* __restrict__ scratch) {
+  const int* scnt = (const int*)(smem + OFF_SCNT);
   const int q = w * 32 + (lane & 31);
-  const bool need = (lane < 32) && (cnt[q] >= HW);
+  bool need = false;
+  if (lane < 32) {
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) need |= scnt[q * NGRP + g] > limit;
+  }
   unsigned long long m = __ballot(need);
   while (m) {
     const int b = __builtin_ctzll(m);
     m &= m - 1;
     const int qq = w * 32 + b;
-    compact_query(wg_sc + (size_t)qq * CAP, wg_row + (size_t)qq * CAP, qq, k, lane);
+    compact_query(wg_sc + (size_t)qq * QCAP, wg_row + (size_t)qq * QCAP, qq, k, lane, scratch);
   }
-  if (record_pre && lane < 32) cnt_pre[q] = cnt[q];
 }
 
 template <int DT>
@@ -200,7 +240,9 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;
+#ifdef MRAG_DIAG
   int stamp_n = 0;
+#endif
   MRAG_STAMP(0);
 
   // ---- block -> (query tile t, corpus split s) ------------------------------------------
@@ -230,52 +272,61 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     }
   }
   const int wg = t * p.S + s;
-  uint32_t* wg_sc = p.list_sc + (size_t)wg * TQ * CAP;
-  uint32_t* wg_row = p.list_row + (size_t)wg * TQ * CAP;
+  uint32_t* wg_sc = p.list_sc + (size_t)wg * TQ * QCAP;
+  uint32_t* wg_row = p.list_row + (size_t)wg * TQ * QCAP;
   const int tile_lo = (int)(((long long)s * p.n_ctiles) / p.S);
   const int tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
   const int ksteps = p.ksteps;
-  const int n_steps = (tile_hi - tile_lo) * ksteps;
 
   float* tau_c = (float*)(smem + OFF_TAU);
-  int* cnt = (int*)(smem + OFF_CNT);
-  int* cnt_pre = (int*)(smem + OFF_CNTPRE);
-  uint32_t* stat = (uint32_t*)(smem + OFF_STAT);   // [2][256] orderable bits, atomicMin target
+  int* kcnt = (int*)(smem + OFF_KCNT);
+  int* scnt = (int*)(smem + OFF_SCNT);
+  uint32_t* stat = (uint32_t*)(smem + OFF_STAT);   // [2][256] orderable bits, ds_min target
   int* flags = (int*)(smem + OFF_FLAGS);
+  uint32_t* rm = (uint32_t*)(smem + OFF_RM);
   if (tid < TQ) {
     tau_c[tid] = -INFINITY;
-    cnt[tid] = 0;
-    cnt_pre[tid] = 0;
+    kcnt[tid] = 0;
     stat[tid] = 0xFFFFFFFFu;
     stat[TQ + tid] = 0xFFFFFFFFu;
   }
+  for (int i = tid; i < TQ * NGRP; i += NTHR) scnt[i] = 0;
   if (tid == 0) flags[0] = 0;
 
   // ---- LDS-DMA source offsets: wave w fills 1-KiB chunks 4w..4w+3 of each operand ---------
   // chunk c = 8 rows x 128 B; lane l -> row r = 8c + (l>>3), physical 16-B chunk l&7,
-  // logical chunk (l&7) ^ ((r>>1)&7)
-  int src_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (4 * w + i) * 8 + (lane >> 3);
-    const int kc = (lane & 7) ^ ((r >> 1) & 7);
-    src_off[i] = r * p.ld + kc * 8;
-  }
-  const uint16_t* qbase = p.queries + (size_t)t * TQ * p.ld;
+  // logical chunk (l&7) ^ ((r>>1)&7) = (l&7) ^ ((4c + (l>>4)) & 7).  Chunks c and c+2 share the
+  // per-lane part, so ONE 32-bit voffset per chunk parity is enough; the chunk's row block goes
+  // into the scalar base (scalar-base + 32-bit-voffset form, no 64-bit per-lane addresses).
+  const uint32_t row_b = (uint32_t)p.ld * 2u;                       // bytes per row
+  const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);        // even chunks
+  const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);  // odd chunks
+  const char* q_ptr = (const char*)(p.queries + (size_t)t * TQ * p.ld) + (size_t)(4 * w) * 8 * row_b;
+  const size_t tile_bytes = (size_t)TM * p.ld * 2;
+  const uint32_t chunk_b = 8u * row_b;                               // 8 rows
 
-  auto stage = [&](int step, int buf) {
-    const int tile = tile_lo + step / ksteps;
-    const int kk = step - (step / ksteps) * ksteps;
-    const uint16_t* a = p.corpus + (size_t)tile * TM * p.ld + kk * BK;
-    const uint16_t* b = qbase + kk * BK;
-    char* la = smem + buf * STAGE_BYTES + (4 * w) * 1024;
-    char* lb = la + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr)(a + src_off[i]), (lds_vptr)(la + i * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((glb_vptr)(b + src_off[i]), (lds_vptr)(lb + i * 1024), 16, 0, 0);
+  // One stage = 8 LDS-DMA loads per wave (4 corpus chunks, 4 query chunks), issued from inline
+  // asm.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt below.
+  // M0 (LDS destination base) is written inside the statement that uses it and restored after.
+  auto stage = [&](const char* a, const char* b, int buf) {
+    const uint32_t la = (uint32_t)(buf * STAGE_BYTES + (4 * w) * 1024);   // wave-uniform LDS byte address
+    const char *a1 = a + chunk_b, *a2 = a1 + chunk_b, *a3 = a2 + chunk_b;
+    const char *b1 = b + chunk_b, *b2 = b1 + chunk_b, *b3 = b2 + chunk_b;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+        "s_add_u32 m0, m0, 0x7400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %10\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_e), "v"(voff_o), "s"(a), "s"(a1), "s"(a2), "s"(a3), "s"(b), "s"(b1), "s"(b2), "s"(b3), "s"(la)
+        : "memory", "scc");
   };
 
   // ---- fragment read offsets ------------------------------------------------------------
@@ -284,30 +335,41 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   const int a_rd = (wm * 128 + frow) * 128;
   const int b_rd = A_BYTES + (wn * 64 + frow) * 128;
   const int ph0 = (((lane >> 4)) ^ fsw) * 16;      // k sub-step 0: logical chunks 0..3
-  const int ph1 = ((4 + (lane >> 4)) ^ fsw) * 16;  // k sub-step 1: logical chunks 4..7
+  // k sub-step 1 reads logical chunks 4..7: ((4 + x) ^ fsw) * 16 == ph0 ^ 64
 
   f32x4 acc[8][4];
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // running two largest per-tile maxima of this lane, per query column (k <= 16 certificate)
-  float rm1[4], rm2[4];
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) rm1[nf] = rm2[nf] = -INFINITY;
 
-  if (n_steps > 0) stage(0, 0);
+  // prefetch cursor: (tile, k step) of the NEXT stage to issue, advanced with scalar adds only
+  const int n_tiles = tile_hi - tile_lo;
+  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(4 * w) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
+  int pf_kk = 0, pf_left = n_tiles * ksteps;
+  int buf = 0;
+  if (pf_left > 0) {
+    stage(a_tile, q_ptr, 0);
+    --pf_left;
+    if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   MRAG_STAMP(1);
 
-  for (int step = 0; step < n_steps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < n_steps) stage(step + 1, buf ^ 1);
+  for (int ti = 0; ti < n_tiles; ++ti) {
+   for (int kk = 0; kk < ksteps; ++kk) {
+    if (pf_left > 0 && !MRAG_DBG(4)) {   // diag 4: ablate the loads
+      stage(a_tile + pf_kk * (BK * 2), q_ptr + pf_kk * (BK * 2), buf ^ 1);
+      --pf_left;
+      if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+    }
 
     const char* sb = smem + buf * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int ph = ks ? ph1 : ph0;
+      if (MRAG_DBG(8)) break;   // diag 8: ablate LDS reads + MFMA
+      const int ph = ks ? (ph0 ^ 64) : ph0;
       frag af[8], bfr[4];
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) af[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph);
@@ -318,9 +380,9 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = Mfma<DT>::run(af[mf], bfr[nf], acc[mf][nf]);
     }
+    buf ^= 1;
 
-    const int kk = step % ksteps;
-    if (kk == ksteps - 1 && (p.dbg & 1)) {
+    if (kk == ksteps - 1 && MRAG_DBG(1)) {
       // ablation: no top-k filter; keep the accumulators observable, then clear them
       float x = 0.f;
 #pragma unroll
@@ -330,17 +392,17 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           x += acc[mf][nf][0] + acc[mf][nf][1] + acc[mf][nf][2] + acc[mf][nf][3];
           acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-      if (x == 123456.789f) cnt[0] = 1;
+      if (x == 123456.789f) kcnt[0] = 1;
     } else if (kk == ksteps - 1) {
       // =========================== fused top-k epilogue ===================================
-      const int ti = step / ksteps;  // tile index inside the split
-      const int tile = tile_lo + ti;
+      const int tile = tile_lo + ti;   // ti = tile index inside the split
       // lane-derived values are recomputed from an opaque copy so that nothing the epilogue
       // needs is hoisted out of the K loop (the loop body is near the 256-VGPR budget)
       int elane = lane;
       asm volatile("" : "+v"(elane));
       const int row0 = tile * TM + wm * 128 + (elane >> 4) * 4;  // + mf*16 + j
       const int q0 = wn * 64 + (elane & 15);                     // + nf*16
+      const int grp = wm * 4 + (elane >> 4);                     // this lane's segment of each of its queries
       const bool certify = p.k <= K_CERT;
       MRAG_STAMP(10 + (ti == 0 ? 0 : 100));
       if ((tile + 1) * TM > p.n_rows) {
@@ -353,23 +415,12 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
               for (int nf = 0; nf < 4; ++nf) acc[mf][nf][j] = -INFINITY;
             }
       }
-      // per-lane maximum of the tile, per query column
-      float tmax[4];
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        float m = acc[0][nf][0];
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) m = fmaxf(m, acc[mf][nf][j]);
-        tmax[nf] = m;
-      }
       float thr[4];
       uint32_t* stat_cur = stat + (ti & 1) * TQ;        // certificate built from tiles <= ti
       uint32_t* stat_prev = stat + ((ti & 1) ^ 1) * TQ;  // certificate from tiles < ti
       if (ti == 0) {
-        // ---- first tile: tau0 = min over the query's 8 lane groups of the group's 2nd largest
-        // score IN this tile; >= 16 rows are >= tau0, so pass on '>=' (as '> next_below').
+        // ---- first tile: tau0 = min over the query's 8 lanes of the lane's 2nd largest score
+        // IN this tile; >= 16 rows are >= tau0, so pass on '>=' (as '> next_below').
         if (certify) {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {
@@ -382,17 +433,17 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
                 m2 = fmaxf(m2, fminf(m1, v));
                 m1 = fmaxf(m1, v);
               }
-            rm1[nf] = m1;
-            rm2[nf] = m2;
+            lds_store_u32(&rm[(nf * 2 + 0) * NTHR + tid], __float_as_uint(m1));
+            lds_store_u32(&rm[(nf * 2 + 1) * NTHR + tid], __float_as_uint(m2));
             float x = m2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
-            if (elane < 16) atomicMin(&stat_cur[q0 + nf * 16], f32_ord(x));
+            if (elane < 16) lds_min_u32(&stat_cur[q0 + nf * 16], f32_ord(x));
           }
           __syncthreads();
           MRAG_STAMP(11);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
+          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(lds_load_u32(&stat_cur[q0 + nf * 16])));
         } else {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) thr[nf] = -INFINITY;
@@ -400,66 +451,71 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       } else {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          const float sc = certify ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
-          thr[nf] = fmaxf(sc, tau_c[q0 + nf * 16]);
+          const float sc = certify ? ord_f32(lds_load_u32(&stat_prev[q0 + nf * 16])) : -INFINITY;
+          thr[nf] = fmaxf(sc, __uint_as_float(lds_load_u32(&tau_c[q0 + nf * 16])));
         }
       }
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
         if (t * TQ + q0 + nf * 16 >= p.nq) thr[nf] = INFINITY;   // padding queries never list anything
+      int cseg[4];   // this lane's segment fill, per query column
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) cseg[nf] = (int)lds_load_u32(&scnt[(q0 + nf * 16) * NGRP + grp]);
+      MRAG_STAMP(21);
 
-      // ---- push: attempt 0 = whole tile at once; on list overflow replay in 4 sub-rounds ------
+      // ---- push: attempt 0 = whole tile at once; a full segment -> replay in 4 sub-rounds ------
       int attempt = 0, round = 0;
+      float tmax[4];
       while (true) {
-        const uint32_t srmask = attempt ? (0xFFu << (8 * round)) : 0xFFFFFFFFu;
         int rbase = row0;
-        asm volatile("" : "+v"(rbase));   // keep the 128 {score,row} store operands from being pre-formed (and spilled) outside this loop
+        asm volatile("" : "+v"(rbase));   // keep the 128 store operands from being pre-formed outside this loop
+        // Two-level filter.  Always: max of each 4-score group (one MFMA accumulator) and a
+        // wave-uniform test against the column's threshold.  Only a group in which some lane
+        // beats its threshold stores entries (compare + two predicated dword stores each).
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          if (!__any(tmax[nf] > thr[nf])) continue;
-          uint32_t mask = 0;
-#pragma unroll
-          for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mask |= (acc[mf][nf][j] > thr[nf]) ? (1u << (mf * 4 + j)) : 0u;
-          mask &= srmask;
           const int q = q0 + nf * 16;
-          const int n_new = __popc(mask);
-          int base = 0;
-          if (n_new) {
-            base = atomicAdd(&cnt[q], n_new);
-            if (base + n_new > CAP) flags[0] = 1;
-          }
-          uint32_t* lsc = wg_sc + (size_t)q * CAP;
-          uint32_t* lrow = wg_row + (size_t)q * CAP;
+          const size_t seg0 = (size_t)q * QCAP + KEPT + grp * SEG;
+          uint32_t* lsc = wg_sc + seg0;
+          uint32_t* lrow = wg_row + seg0;
+          float tm = -INFINITY;
+          int c = cseg[nf];
 #pragma unroll
           for (int mf = 0; mf < 8; ++mf) {
-            if (!__any((mask >> (mf * 4)) & 0xFu)) continue;
+            const f32x4 a = acc[mf][nf];
+            const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+            tm = fmaxf(tm, m4);
+            if (attempt && (mf >> 1) != round) continue;      // replay: 2 accumulators (<= 8 pushes/segment) per round
+            if (!__any(m4 > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const int bit = mf * 4 + j;
-              if (mask & (1u << bit)) {
-                const int slot = base + __popc(mask & ((1u << bit) - 1u));
-                if (slot < CAP) {
-                  lsc[slot] = __float_as_uint(acc[mf][nf][j]);
-                  lrow[slot] = (uint32_t)(rbase + mf * 16 + j);
+              if (a[j] > thr[nf]) {
+                if (c < SEG) {
+                  lsc[c] = __float_as_uint(a[j]);
+                  lrow[c] = (uint32_t)(rbase + mf * 16 + j);
                 }
+                ++c;
               }
             }
           }
+          cseg[nf] = c;
+          tmax[nf] = tm;
         }
-        if (attempt == 0 && certify) {
+        if ((cseg[0] > SEG) | (cseg[1] > SEG) | (cseg[2] > SEG) | (cseg[3] > SEG)) lds_store_u32(&flags[0], 1u);
+        MRAG_STAMP(22);
+        if (attempt == 0 && certify && ti != 0) {
           // fold this tile's maxima into the running certificate used from the NEXT tile on
-          if (ti != 0) {
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-              rm2[nf] = fmaxf(rm2[nf], fminf(rm1[nf], tmax[nf]));
-              rm1[nf] = fmaxf(rm1[nf], tmax[nf]);
-              float x = rm2[nf];
-              x = fminf(x, __shfl_xor(x, 16));
-              x = fminf(x, __shfl_xor(x, 32));
-              if (elane < 16) atomicMin(&stat_cur[q0 + nf * 16], f32_ord(x));
-            }
+          for (int nf = 0; nf < 4; ++nf) {
+            const float o1 = __uint_as_float(lds_load_u32(&rm[(nf * 2 + 0) * NTHR + tid]));
+            const float o2 = __uint_as_float(lds_load_u32(&rm[(nf * 2 + 1) * NTHR + tid]));
+            const float n2 = fmaxf(o2, fminf(o1, tmax[nf])), n1 = fmaxf(o1, tmax[nf]);
+            lds_store_u32(&rm[(nf * 2 + 0) * NTHR + tid], __float_as_uint(n1));
+            lds_store_u32(&rm[(nf * 2 + 1) * NTHR + tid], __float_as_uint(n2));
+            float x = n2;
+            x = fminf(x, __shfl_xor(x, 16));
+            x = fminf(x, __shfl_xor(x, 32));
+            if (elane < 16) lds_min_u32(&stat_cur[q0 + nf * 16], f32_ord(x));
           }
         }
         MRAG_STAMP(12 + (ti == 0 ? 0 : 100));
@@ -467,33 +523,35 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         MRAG_STAMP(13 + (ti == 0 ? 0 : 100));
         if (attempt == 0) {
           if (!flags[0]) {
-            compact_owned(wg_sc, wg_row, w, elane, p.k, true);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];   // commit
             if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;   // becomes stat_cur of tile ti+1
             break;
           }
-          __syncthreads();               // everyone has seen the flag
-          if (tid < TQ) cnt[tid] = cnt_pre[tid];
+          __syncthreads();               // everyone has seen the flag; committed counts are still pre-tile
           if (tid == 0) flags[0] = 0;
-          __syncthreads();
           attempt = 1;
           round = 0;
         } else {
-          compact_owned(wg_sc, wg_row, w, elane, p.k, round == 3);
-          __syncthreads();
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];     // commit (cannot overflow)
           if (round == 3) {
             if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;
             break;
           }
           ++round;
+          __syncthreads();
         }
-        if (attempt) {
+        // replay step: make room (every segment <= SEG - 8), then reload counts and thresholds
+        // LDS scratch: the stage buffer this K step has just consumed (free until the next stage() call)
+        compact_owned(wg_sc, wg_row, w, elane, p.k, SEG - 8, (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192));
+        __syncthreads();
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
-            const float sc = (certify && ti != 0) ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
-            float th = fmaxf(sc, tau_c[q0 + nf * 16]);
-            if (t * TQ + q0 + nf * 16 >= p.nq) th = INFINITY;
-            thr[nf] = fmaxf(thr[nf], th);
-          }
+        for (int nf = 0; nf < 4; ++nf) {
+          cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
+          float th = tau_c[q0 + nf * 16];
+          if (t * TQ + q0 + nf * 16 >= p.nq) th = INFINITY;
+          thr[nf] = fmaxf(thr[nf], th);
         }
       }
       MRAG_STAMP(14 + (ti == 0 ? 0 : 100));
@@ -501,19 +559,28 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // The K loop's lane constants may have been spilled around the epilogue.  Touch them HERE so
+      // that the compiler's reload (and its s_waitcnt vmcnt, which would also drain the LDS-DMA
+      // prefetch it cannot see) sits at the end of the epilogue, not inside the next K step.
+      asm volatile("" :: "v"(a_rd), "v"(b_rd), "v"(ph0), "v"(voff_e), "v"(voff_o));
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage prefetched during this step has landed
     __syncthreads();
+   }
   }
 
   __syncthreads();
   MRAG_STAMP(99);
-  if (tid < TQ) p.counts[(size_t)wg * TQ + tid] = min(cnt[tid], CAP);
+  for (int i = tid; i < TQ * NCNT; i += NTHR) {
+    const int q = i / NCNT, c = i - q * NCNT;
+    p.counts[(size_t)wg * TQ * NCNT + i] = c == 0 ? kcnt[q] : min(scnt[q * NGRP + c - 1], SEG);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: one wave per query selects the k best of the S candidate lists.
+// K4: one wave per query selects the k best of the S workgroups' lists (kept + 8 segments each).
 // ------------------------------------------------------------------------------------------
-constexpr int MERGE_LDS_ENT = 4096;
+constexpr int MERGE_LDS_ENT = 8192;   // 64 KiB of keys per workgroup
 
 struct MergeParams {
   const uint32_t* list_sc;
@@ -536,6 +603,26 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
   return v;
 }
 
+// k best keys of keys[0..fill) -> best[0..nsel), best first (keys are unique: the row is in the key)
+__device__ __forceinline__ int merge_extract(const uint64_t* keys, int fill, int k, uint64_t* best, int lane) {
+  uint64_t last = ~0ull;
+  const int nsel = min(k, fill);
+  for (int i = 0; i < nsel; ++i) {
+    uint64_t m = 0ull;
+    for (int e = lane; e < fill; e += 64) {
+      const uint64_t key = keys[e];
+      if (key < last && key > m) m = key;
+    }
+    m = wave_max_u64(m);
+    if (lane == 0) best[i] = m;
+    last = m;
+  }
+  return nsel;
+}
+
+// One wave per query.  The query's candidates sit in S x 9 regions (kept area + 8 lane segments
+// per K2 workgroup); 64 regions are gathered at a time, one region per lane, into LDS at offsets
+// from a wave prefix sum, then the k best are extracted by k wave-wide max passes.
 __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   __shared__ uint64_t keys[MERGE_LDS_ENT];
   __shared__ uint64_t best[KMAX];
@@ -544,46 +631,39 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   if (q >= p.nq) return;
   const int t = (int)(q / TQ), ql = (int)(q % TQ);
   const int k = p.k;
-  int nbest = 0;  // entries of `best` carried into the next chunk
-  int s = 0, pos = 0;
-  bool done = false;
-  while (!done) {
-    // fill keys[0..fill) with carried best + as many list entries as fit
-    int fill = 0;
-    for (int i = lane; i < nbest; i += 64) keys[i] = best[i];
-    fill = nbest;
-    while (s < p.S) {
-      const int wg = t * p.S + s;
-      const int c = p.counts[(size_t)wg * TQ + ql];
-      const uint32_t* lsc = p.list_sc + ((size_t)wg * TQ + ql) * CAP;
-      const uint32_t* lrow = p.list_row + ((size_t)wg * TQ + ql) * CAP;
-      const int take = min(c - pos, MERGE_LDS_ENT - fill);
-      for (int i = lane; i < take; i += 64) {
-        keys[fill + i] = make_key(lsc[pos + i], lrow[pos + i]);
-      }
-      fill += take;
-      pos += take;
-      if (pos >= c) { ++s; pos = 0; }
-      if (fill >= MERGE_LDS_ENT) break;
+  const int n_regions = p.S * NCNT;
+  int fill = 0;
+  for (int r0 = 0; r0 < n_regions; r0 += 64) {
+    const int r = r0 + lane;
+    int c = 0;
+    size_t base = 0;
+    if (r < n_regions) {
+      const int s = r / NCNT, part = r - s * NCNT;
+      const size_t wq = (size_t)(t * p.S + s) * TQ + ql;
+      c = p.counts[wq * NCNT + part];
+      base = wq * QCAP + (part == 0 ? 0 : KEPT + (part - 1) * SEG);
     }
-    done = (s >= p.S);
-    __syncthreads();
-    // extract the k best of keys[0..fill)
-    uint64_t last = ~0ull;
-    const int nsel = min(k, fill);
-    for (int i = 0; i < nsel; ++i) {
-      uint64_t m = 0ull;
-      for (int e = lane; e < fill; e += 64) {
-        const uint64_t key = keys[e];
-        if (key < last && key > m) m = key;
-      }
-      m = wave_max_u64(m);
-      if (lane == 0) best[i] = m;
-      last = m;
+    int incl = c;   // inclusive wave prefix sum
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
     }
-    nbest = nsel;
-    __syncthreads();
+    const int total = __shfl(incl, 63);
+    if (fill + total > MERGE_LDS_ENT) {   // make room: fold what is staged into the running best
+      __syncthreads();
+      const int nb = merge_extract(keys, fill, k, best, lane);
+      __syncthreads();
+      for (int i = lane; i < nb; i += 64) keys[i] = best[i];
+      fill = nb;
+    }
+    const int off0 = fill + incl - c;
+    for (int i = 0; i < c; ++i) keys[off0 + i] = make_key(p.list_sc[base + i], p.list_row[base + i]);
+    fill += total;
   }
+  __syncthreads();
+  const int nbest = merge_extract(keys, fill, k, best, lane);
+  __syncthreads();
   for (int i = lane; i < k; i += 64) {
     float sc = -INFINITY;
     int64_t id = -1;
@@ -831,8 +911,8 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
     MRAG_TRY(launch_prep_rows(qsrc, q_dtype, nq, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                               normalize && ix->metric == MRAG_METRIC_COSINE, stream));
-    MRAG_TRY(ix->lists.ensure(grid * TQ * CAP * 8));
-    MRAG_TRY(ix->counts.ensure(grid * TQ * sizeof(int)));
+    MRAG_TRY(ix->lists.ensure(grid * TQ * QCAP * 8));
+    MRAG_TRY(ix->counts.ensure(grid * TQ * NCNT * sizeof(int)));
 
     BfParams p;
     p.corpus = ix->rows;
@@ -846,11 +926,14 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     p.S = S;
     p.k = k;
     p.xcd_map = xcd;
+    p.dbg = 0;
+#ifdef MRAG_DIAG
     {
       static int dbg = -1;
       if (dbg < 0) { const char* e = getenv("MRAG_DEBUG_FLAGS"); dbg = e ? atoi(e) : 0; }
       p.dbg = dbg;
     }
+#endif
     p.stamps = nullptr;
     if (p.dbg & 16) {
       if (!g_stamps) MRAG_HIP(hipMalloc((void**)&g_stamps, 128 * 8));
@@ -858,7 +941,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       p.stamps = g_stamps;
     }
     p.list_sc = (uint32_t*)ix->lists.p;
-    p.list_row = p.list_sc + grid * TQ * CAP;
+    p.list_row = p.list_sc + grid * TQ * QCAP;
     p.counts = (int*)ix->counts.p;
     static bool attr_done[2] = {false, false};
     if (ix->dtype == MRAG_F16) {
