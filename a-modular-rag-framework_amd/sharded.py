@@ -49,8 +49,9 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
             bufs["hs"] = torch.empty((world, q, k), dtype=torch.float32, pin_memory=True)
             bufs["hi"] = torch.empty((world, q, k), dtype=torch.int64, pin_memory=True)
     gs, gi = bufs["gs"], bufs["gi"]
-    dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
-    dist.all_gather_into_tensor(gi, local_ids.contiguous(), group=group)
+    # output = the inputs concatenated along dim 0 (the layout both nccl and gloo accept)
+    dist.all_gather_into_tensor(gs.view(world * q, k), local_scores.contiguous(), group=group)
+    dist.all_gather_into_tensor(gi.view(world * q, k), local_ids.contiguous(), group=group)
     if gs.is_cuda:
         hs, hi = bufs["hs"], bufs["hi"]
         hs.copy_(gs, non_blocking=True)

@@ -1,0 +1,121 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/mrag.h declares; compute
+entry points fail loudly without a GPU; host merge; the N>1 exchange path on gloo (world 2)."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    from mrag_amd import _native as N
+    header = (ROOT / "include" / "mrag.h").read_text()
+    declared = set(re.findall(r"\b(mrag_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mrag_handle"}
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    lib = N.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.mrag_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", str(N.lib_path())], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(mrag_[a-z0-9_]+)$", out, flags=re.M))
+    assert declared <= exported
+
+
+def test_no_silent_cpu_fallback():
+    if _has_gpu():
+        pytest.skip("GPU present")
+    from mrag_amd import _native as N
+    from mrag_amd.index import DenseIndex, cosine_f64
+    assert N.device_count() == 0
+    with pytest.raises(N.MragError) as e:
+        DenseIndex(64)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+    with pytest.raises(N.MragError):
+        cosine_f64(np.ones(4), np.ones((2, 4)))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from mrag_amd import _native as N
+    monkeypatch.setattr(N, "_LIB", None)
+    monkeypatch.setenv("MRAG_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(N.MragLibraryMissing):
+        N.load()
+    monkeypatch.delenv("MRAG_HIP_LIB")
+    monkeypatch.setattr(N, "_LIB", None)
+    N.load()
+
+
+def test_host_merge_matches_oracle():
+    from mrag_amd.index import topk_merge
+    from oracle import dense_search as ds
+    rng = np.random.default_rng(0)
+    nparts, nq, k = 8, 700, 10
+    sc = rng.integers(0, 50, size=(nparts, nq, k)).astype(np.float32) / 7     # many exact ties
+    sc = -np.sort(-sc, axis=2)
+    ids = rng.permutation(nparts * nq * k).reshape(nparts, nq, k).astype(np.int64)
+    ids[3, :, 7:] = -1                                                       # empty slots
+    sc[3, :, 7:] = -np.inf
+    v, i = topk_merge(sc, ids)
+    ov, oi = ds.merge_topk([sc[p] for p in range(nparts)], [ids[p] for p in range(nparts)], k)
+    assert (i == oi).all() and (v == ov.astype(np.float32)).all()
+    v1, i1 = topk_merge(sc, ids, nthreads=1)
+    assert (i1 == i).all()
+    vs, is_ = topk_merge(sc[:1, :, :3] * 0 - np.inf, ids[:1, :, :3] * 0 - 1)
+    assert (is_ == -1).all() and np.isneginf(vs).all()
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MRAG_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from mrag_amd.sharded import ShardedDenseIndex, shard_bounds
+from oracle import dense_search as ds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n, nq, d, k = 3001, 37, 48, 10
+c16 = ds.normalize_round(ds.make_gaussian(n, d, 1234)); q16 = ds.normalize_round(ds.make_gaussian(nq, d, 5678))
+lo, hi = shard_bounds(n, world, rank)
+def local(q, k):                       # the oracle plays the per-GPU kernel in this CPU test
+    v, i = ds.brute_force_topk(q, c16[lo:hi], k)
+    return v.astype(np.float32), np.where(i >= 0, i + lo, i)
+sh = ShardedDenseIndex(d, n, rank, world, local_search=local)
+assert (sh.lo, sh.hi) == (lo, hi)
+for _ in range(2):                     # second call reuses the gather buffers
+    v, i = sh.search(q16, k)
+rv, ri = ds.brute_force_topk(q16, c16, k)
+assert (i == ri).all(), "sharded ids differ from unsharded"
+assert np.array_equal(v, rv.astype(np.float32))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_exchange_on_gloo(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MRAG_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29500 + world), str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == world
+
+
+def test_shard_bounds_cover_everything():
+    from mrag_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 1_000_000):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
