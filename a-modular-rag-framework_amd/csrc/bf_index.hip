@@ -92,6 +92,8 @@ struct BfParams {
   int S;                    // corpus splits
   int k;
   int xcd_map;              // 1: S % 8 == 0, use the XCD-aware block -> (t, s) map
+  const int* wg_desc;       // descriptor mode (IVF list scan): per workgroup {query row0, valid queries,
+                            // first tile, end tile, end row, 0,0,0}; NULL = dense (t, s) decomposition
   int dbg;                  // development ablations (MRAG_DEBUG_FLAGS); 0 in production
   long long* stamps;        // dbg & 16: block 0 / wave 0 writes s_memtime stamps here
   uint32_t* list_sc;        // [T*S][256][QCAP]  score bits   (SoA: two dword stores per push)
@@ -245,9 +247,15 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 #endif
   MRAG_STAMP(0);
 
-  // ---- block -> (query tile t, corpus split s) ------------------------------------------
-  int t, s;
-  {
+  // ---- block -> (query tile, corpus tile range) ----------------------------------------------
+  int wg, q_row0, nq_local, tile_lo, tile_hi, rows_end;
+  if (p.wg_desc) {
+    // descriptor mode: one workgroup = one IVF list x up to 256 of the queries that probe it
+    const int* d = p.wg_desc + (size_t)blockIdx.x * 8;
+    wg = blockIdx.x;
+    q_row0 = d[0]; nq_local = d[1]; tile_lo = d[2]; tile_hi = d[3]; rows_end = d[4];
+  } else {
+    int t, s;
     const int b = blockIdx.x;
     if (p.xcd_map) {
       const int x = b & 7, idx = b >> 3, sx = p.S >> 3;
@@ -270,12 +278,15 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       s = b % p.S;
       t = b / p.S;
     }
+    wg = t * p.S + s;
+    q_row0 = t * TQ;
+    nq_local = p.nq - q_row0;
+    tile_lo = (int)(((long long)s * p.n_ctiles) / p.S);
+    tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
+    rows_end = p.n_rows;
   }
-  const int wg = t * p.S + s;
   uint32_t* wg_sc = p.list_sc + (size_t)wg * TQ * QCAP;
   uint32_t* wg_row = p.list_row + (size_t)wg * TQ * QCAP;
-  const int tile_lo = (int)(((long long)s * p.n_ctiles) / p.S);
-  const int tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
   const int ksteps = p.ksteps;
 
   float* tau_c = (float*)(smem + OFF_TAU);
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   const uint32_t row_b = (uint32_t)p.ld * 2u;                       // bytes per row
   const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);        // even chunks
   const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);  // odd chunks
-  const char* q_ptr = (const char*)(p.queries + (size_t)t * TQ * p.ld) + (size_t)(4 * w) * 8 * row_b;
+  const char* q_ptr = (const char*)(p.queries + (size_t)q_row0 * p.ld) + (size_t)(4 * w) * 8 * row_b;
   const size_t tile_bytes = (size_t)TM * p.ld * 2;
   const uint32_t chunk_b = 8u * row_b;                               // 8 rows
 
@@ -405,12 +416,12 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       const int grp = wm * 4 + (elane >> 4);                     // this lane's segment of each of its queries
       const bool certify = p.k <= K_CERT;
       MRAG_STAMP(10 + (ti == 0 ? 0 : 100));
-      if ((tile + 1) * TM > p.n_rows) {
+      if ((tile + 1) * TM > rows_end) {
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (row0 + mf * 16 + j >= p.n_rows) {
+            if (row0 + mf * 16 + j >= rows_end) {
 #pragma unroll
               for (int nf = 0; nf < 4; ++nf) acc[mf][nf][j] = -INFINITY;
             }
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       }
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf)
-        if (t * TQ + q0 + nf * 16 >= p.nq) thr[nf] = INFINITY;   // padding queries never list anything
+        if (q0 + nf * 16 >= nq_local) thr[nf] = INFINITY;   // padding queries never list anything
       int cseg[4];   // this lane's segment fill, per query column
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) cseg[nf] = (int)lds_load_u32(&scnt[(q0 + nf * 16) * NGRP + grp]);
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         for (int nf = 0; nf < 4; ++nf) {
           cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
           float th = tau_c[q0 + nf * 16];
-          if (t * TQ + q0 + nf * 16 >= p.nq) th = INFINITY;
+          if (q0 + nf * 16 >= nq_local) th = INFINITY;
           thr[nf] = fmaxf(thr[nf], th);
         }
       }
@@ -589,6 +600,9 @@ struct MergeParams {
   int T, S, k;
   int64_t nq;
   int64_t id_base;
+  const int2* pair_loc;     // descriptor mode: [nq][nprobe] (workgroup, slot) of each probe, wg < 0 = none
+  int nprobe;
+  const int64_t* row_ids;   // descriptor mode: stored position -> original row (ties break on it)
   float* out_scores;   // [nq][k]
   int64_t* out_ids;    // [nq][k]
 };
@@ -631,7 +645,8 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   if (q >= p.nq) return;
   const int t = (int)(q / TQ), ql = (int)(q % TQ);
   const int k = p.k;
-  const int n_regions = p.S * NCNT;
+  const int n_groups = p.pair_loc ? p.nprobe : p.S;
+  const int n_regions = n_groups * NCNT;
   int fill = 0;
   for (int r0 = 0; r0 < n_regions; r0 += 64) {
     const int r = r0 + lane;
@@ -639,8 +654,16 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
     size_t base = 0;
     if (r < n_regions) {
       const int s = r / NCNT, part = r - s * NCNT;
-      const size_t wq = (size_t)(t * p.S + s) * TQ + ql;
-      c = p.counts[wq * NCNT + part];
+      size_t wq;
+      bool ok = true;
+      if (p.pair_loc) {
+        const int2 loc = p.pair_loc[q * p.nprobe + s];
+        ok = loc.x >= 0;
+        wq = (size_t)(ok ? loc.x : 0) * TQ + (size_t)loc.y;
+      } else {
+        wq = (size_t)(t * p.S + s) * TQ + ql;
+      }
+      if (ok) c = p.counts[wq * NCNT + part];
       base = wq * QCAP + (part == 0 ? 0 : KEPT + (part - 1) * SEG);
     }
     int incl = c;   // inclusive wave prefix sum
@@ -658,7 +681,11 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
       fill = nb;
     }
     const int off0 = fill + incl - c;
-    for (int i = 0; i < c; ++i) keys[off0 + i] = make_key(p.list_sc[base + i], p.list_row[base + i]);
+    for (int i = 0; i < c; ++i) {
+      uint32_t row = p.list_row[base + i];
+      if (p.row_ids) row = (uint32_t)p.row_ids[row];
+      keys[off0 + i] = make_key(p.list_sc[base + i], row);
+    }
     fill += total;
   }
   __syncthreads();
@@ -710,7 +737,9 @@ struct BfIndex : Object {
   }
 };
 
+#ifdef MRAG_DIAG
 static long long* g_stamps = nullptr;  // diagnostic s_memtime stamps (MRAG_DEBUG_FLAGS & 16)
+#endif
 
 static size_t dtype_size(int dt) {
   switch (dt) { case MRAG_F32: return 4; case MRAG_F16: case MRAG_BF16: return 2; case MRAG_F64: return 8; default: return 0; }
@@ -742,6 +771,119 @@ static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
   if (S > n_ctiles) S = (n_ctiles / 8) * 8;
   *S_out = S;
   *xcd_out = 1;
+}
+
+
+int bf_max_k() { return KMAX; }
+int64_t bf_round_rows(int64_t n) { return round_up(n, TM); }
+
+// Query batches are cut so that one launch keeps its candidate lists (4.6 KB per workgroup and
+// query) within a few GB: at most 64 query tiles (16 384 queries) per launch.
+constexpr int MAX_QTILES_PER_LAUNCH = 64;
+
+int bf_launch(const BfLaunch& a) {
+  if (a.k <= 0 || a.k > KMAX) return fail(MRAG_ERR_UNSUPPORTED, "k = %d outside 1..%d", a.k, KMAX);
+  hipStream_t stream = a.stream;
+  static bool attr_done[2] = {false, false};
+  const int di = a.dtype == MRAG_F16 ? 0 : 1;
+  if (!attr_done[di]) {
+    if (di == 0) MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    else MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr_done[di] = true;
+  }
+  BfParams p;
+  p.corpus = a.corpus;
+  p.ld = a.ld;
+  p.ksteps = a.ld / BK;
+  p.k = a.k;
+  p.dbg = 0;
+  p.stamps = nullptr;
+#ifdef MRAG_DIAG
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MRAG_DEBUG_FLAGS"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+    if (p.dbg & 16) {
+      if (!g_stamps) MRAG_HIP(hipMalloc((void**)&g_stamps, 128 * 8));
+      MRAG_HIP(hipMemsetAsync(g_stamps, 0, 128 * 8, stream));
+      p.stamps = g_stamps;
+    }
+  }
+#endif
+  if (a.ev_k2_begin) MRAG_HIP(hipEventRecord(a.ev_k2_begin, stream));
+  if (a.wg_desc) {
+    // ---- descriptor mode: one launch, one merge -------------------------------------------
+    const size_t grid = (size_t)a.n_wg;
+    MRAG_TRY(a.lists->ensure(grid * TQ * QCAP * 8));
+    MRAG_TRY(a.counts->ensure(grid * TQ * NCNT * sizeof(int)));
+    p.queries = a.queries;
+    p.n_rows = 0; p.n_ctiles = 0; p.nq = 0; p.T = (int)grid; p.S = 1; p.xcd_map = 0;
+    p.wg_desc = a.wg_desc;
+    p.list_sc = (uint32_t*)a.lists->p;
+    p.list_row = p.list_sc + grid * TQ * QCAP;
+    p.counts = (int*)a.counts->p;
+    if (grid) {
+      if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
+      else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
+      MRAG_HIP(hipGetLastError());
+    }
+    if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+    MergeParams mp;
+    mp.list_sc = p.list_sc; mp.list_row = p.list_row; mp.counts = p.counts;
+    mp.T = 0; mp.S = 0; mp.k = a.k; mp.nq = a.nq; mp.id_base = a.id_base;
+    mp.pair_loc = (const int2*)a.pair_loc; mp.nprobe = a.nprobe; mp.row_ids = a.row_ids;
+    mp.out_scores = a.out_scores; mp.out_ids = a.out_ids;
+    if (a.nq) {
+      hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)a.nq), dim3(64), 0, stream, mp);
+      MRAG_HIP(hipGetLastError());
+    }
+    return MRAG_OK;
+  }
+  // ---- dense mode: (query tile, corpus split) grid, query batches of <= 64 tiles ----------------
+  const int n_ctiles = (int)((a.n_rows + TM - 1) / TM);
+  const int T_all = (int)((a.nq + TQ - 1) / TQ);
+  for (int t0 = 0; t0 < T_all; t0 += MAX_QTILES_PER_LAUNCH) {
+    const int T = std::min(MAX_QTILES_PER_LAUNCH, T_all - t0);
+    const int64_t q0 = (int64_t)t0 * TQ;
+    const int64_t nq = std::min<int64_t>(a.nq - q0, (int64_t)T * TQ);
+    int S, xcd;
+    choose_split(T, n_ctiles, &S, &xcd);
+    const size_t grid = (size_t)T * S;
+    MRAG_TRY(a.lists->ensure(grid * TQ * QCAP * 8));
+    MRAG_TRY(a.counts->ensure(grid * TQ * NCNT * sizeof(int)));
+    p.queries = a.queries + (size_t)q0 * a.ld;
+    p.n_rows = (int)a.n_rows;
+    p.n_ctiles = n_ctiles;
+    p.nq = (int)nq;
+    p.T = T; p.S = S; p.xcd_map = xcd;
+    p.wg_desc = nullptr;
+    p.list_sc = (uint32_t*)a.lists->p;
+    p.list_row = p.list_sc + grid * TQ * QCAP;
+    p.counts = (int*)a.counts->p;
+    if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
+    else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
+    MRAG_HIP(hipGetLastError());
+    if (t0 + MAX_QTILES_PER_LAUNCH >= T_all && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+    MergeParams mp;
+    mp.list_sc = p.list_sc; mp.list_row = p.list_row; mp.counts = p.counts;
+    mp.T = T; mp.S = S; mp.k = a.k; mp.nq = nq; mp.id_base = a.id_base;
+    mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
+    mp.out_scores = a.out_scores + (size_t)q0 * a.k;
+    mp.out_ids = a.out_ids + (size_t)q0 * a.k;
+    hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)nq), dim3(64), 0, stream, mp);
+    MRAG_HIP(hipGetLastError());
+#ifdef MRAG_DIAG
+    if (g_stamps && (p.dbg & 16)) {
+      long long hs[128];
+      MRAG_HIP(hipStreamSynchronize(stream));
+      MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[mrag stamps]");
+      for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i) fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
+      fprintf(stderr, "\n");
+    }
+#endif
+  }
+  return MRAG_OK;
 }
 
 }  // namespace mrag
@@ -871,7 +1013,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
   if (!queries || !out_scores || !out_ids) return fail(MRAG_ERR_INVALID, "NULL buffer");
   const size_t esz = dtype_size(q_dtype);
   if (!esz) return fail(MRAG_ERR_INVALID, "unknown query dtype %d", q_dtype);
-  if (nq > (1ll << 24)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one call; batch the queries");
+  if (nq > (1ll << 26)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one call; batch the queries");
   MRAG_TRY(use_device(ix->device));
   hipStream_t stream = (hipStream_t)stream_;
   ix->timed = false;
@@ -892,13 +1034,9 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     MRAG_HIP(hipEventRecord(ix->ev[1], stream));
     MRAG_HIP(hipEventRecord(ix->ev[2], stream));
   } else {
-    const int T = (int)((nq + TQ - 1) / TQ);
-    const int n_ctiles = (int)((ix->n + TM - 1) / TM);
-    int S, xcd;
-    choose_split(T, n_ctiles, &S, &xcd);
-    const size_t grid = (size_t)T * S;
-    // queries -> storage dtype, zero padded to T*256 rows
-    const size_t qbytes = (size_t)T * TQ * ix->ld * 2;
+    // queries -> storage dtype, zero padded to a multiple of 256 rows
+    const int64_t nq_pad = round_up(nq, TQ);
+    const size_t qbytes = (size_t)nq_pad * ix->ld * 2;
     MRAG_TRY(ix->qbuf.ensure(qbytes));
     const void* qsrc = queries;
     if (!queries_is_device) {
@@ -907,78 +1045,24 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       MRAG_HIP(hipMemcpyAsync(ix->stage_in.p, queries, bytes, hipMemcpyHostToDevice, stream));
       qsrc = ix->stage_in.p;
     }
-    if ((int64_t)T * TQ > nq)
+    if (nq_pad > nq)
       MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
     MRAG_TRY(launch_prep_rows(qsrc, q_dtype, nq, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                               normalize && ix->metric == MRAG_METRIC_COSINE, stream));
-    MRAG_TRY(ix->lists.ensure(grid * TQ * QCAP * 8));
-    MRAG_TRY(ix->counts.ensure(grid * TQ * NCNT * sizeof(int)));
-
-    BfParams p;
-    p.corpus = ix->rows;
-    p.queries = (const uint16_t*)ix->qbuf.p;
-    p.ld = ix->ld;
-    p.ksteps = ix->ld / BK;
-    p.n_rows = (int)ix->n;
-    p.n_ctiles = n_ctiles;
-    p.nq = (int)nq;
-    p.T = T;
-    p.S = S;
-    p.k = k;
-    p.xcd_map = xcd;
-    p.dbg = 0;
-#ifdef MRAG_DIAG
-    {
-      static int dbg = -1;
-      if (dbg < 0) { const char* e = getenv("MRAG_DEBUG_FLAGS"); dbg = e ? atoi(e) : 0; }
-      p.dbg = dbg;
-    }
-#endif
-    p.stamps = nullptr;
-    if (p.dbg & 16) {
-      if (!g_stamps) MRAG_HIP(hipMalloc((void**)&g_stamps, 128 * 8));
-      MRAG_HIP(hipMemsetAsync(g_stamps, 0, 128 * 8, stream));
-      p.stamps = g_stamps;
-    }
-    p.list_sc = (uint32_t*)ix->lists.p;
-    p.list_row = p.list_sc + grid * TQ * QCAP;
-    p.counts = (int*)ix->counts.p;
-    static bool attr_done[2] = {false, false};
-    if (ix->dtype == MRAG_F16) {
-      if (!attr_done[0]) { MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_done[0] = true; }
-      MRAG_HIP(hipEventRecord(ix->ev[1], stream));
-      hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-    } else {
-      if (!attr_done[1]) { MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_done[1] = true; }
-      MRAG_HIP(hipEventRecord(ix->ev[1], stream));
-      hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-    }
-    MRAG_HIP(hipGetLastError());
-    MRAG_HIP(hipEventRecord(ix->ev[2], stream));
-
-    MergeParams mp;
-    mp.list_sc = p.list_sc;
-    mp.list_row = p.list_row;
-    mp.counts = p.counts;
-    mp.T = T; mp.S = S; mp.k = k;
-    mp.nq = nq;
-    mp.id_base = ix->id_base;
-    mp.out_scores = d_sc;
-    mp.out_ids = d_id;
-    hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)nq), dim3(64), 0, stream, mp);
-    MRAG_HIP(hipGetLastError());
+    BfLaunch a;
+    a.corpus = ix->rows;
+    a.queries = (const uint16_t*)ix->qbuf.p;
+    a.ld = ix->ld; a.dtype = ix->dtype; a.k = k;
+    a.nq = nq; a.n_rows = ix->n;
+    a.id_base = ix->id_base;
+    a.out_scores = d_sc; a.out_ids = d_id;
+    a.lists = &ix->lists; a.counts = &ix->counts;
+    a.stream = stream;
+    a.ev_k2_begin = ix->ev[1]; a.ev_k2_end = ix->ev[2];
+    MRAG_TRY(bf_launch(a));
   }
   MRAG_HIP(hipEventRecord(ix->ev[3], stream));
   ix->timed = true;
-  if (g_stamps && ix->n > 0) {   // diagnostic build path only (MRAG_DEBUG_FLAGS & 16)
-    long long hs[128];
-    MRAG_HIP(hipStreamSynchronize(stream));
-    MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[mrag stamps]");
-    for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i)
-      fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
-    fprintf(stderr, "\n");
-  }
   if (!out_is_device) {
     MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));

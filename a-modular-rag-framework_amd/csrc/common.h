@@ -63,4 +63,31 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 int launch_prep_rows(const void* src, int src_dtype, int64_t n, int dim, void* dst, int ld,
                      int storage_dtype, int normalize, hipStream_t stream);
 
+
+// One fused similarity + top-k pass (K2) and the candidate merge (K4) over PREPARED operands
+// (storage dtype, padded to `ld`, query buffer padded to a multiple of 256 rows).
+struct BfLaunch {
+  const uint16_t* corpus = nullptr;   // [rows padded to 256][ld]
+  const uint16_t* queries = nullptr;  // dense: [ceil(nq/256)*256][ld]; descriptor mode: gathered [n_wg*256][ld]
+  int ld = 0, dtype = MRAG_F16, k = 0;
+  int64_t nq = 0;                     // queries reported (rows of out_scores / out_ids)
+  int64_t n_rows = 0;                 // dense mode: valid corpus rows
+  // descriptor mode (IVF list scan)
+  const int* wg_desc = nullptr;       // device int[n_wg][8]
+  int n_wg = 0;
+  const void* pair_loc = nullptr;     // device int2[nq][nprobe]
+  int nprobe = 0;
+  const int64_t* row_ids = nullptr;   // device: stored position -> original row
+  int64_t id_base = 0;
+  float* out_scores = nullptr;        // device [nq][k]
+  int64_t* out_ids = nullptr;         // device [nq][k]
+  DevBuf* lists = nullptr;            // workspace (grown as needed)
+  DevBuf* counts = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_k2_begin = nullptr, ev_k2_end = nullptr;   // optional
+};
+int bf_launch(const BfLaunch& a);
+int bf_max_k();
+int64_t bf_round_rows(int64_t n);     // rows rounded up to the kernel's tile (256)
+
 }  // namespace mrag

@@ -1,0 +1,468 @@
+// IVF-flat over the same fused similarity + top-k kernels (BASELINE.json config 5; the reference
+// has no IVF index -- PARITY UNPINNED by the reference, checked against this library's own brute
+// force and the oracle's ivf_search on identical centroids / assignments).
+//
+//   train    spherical k-means on the device: assignment = the dense kernel with the CENTROIDS as
+//            corpus and the rows as queries (k = 1, ties to the lowest list id), update = float
+//            atomics into [nlist][dim] sums, re-normalised and rounded to the storage dtype.
+//   add      rows are normalised/rounded once, kept in arrival order, assigned as above.
+//   search   1) probe lists: dense kernel over the centroids, k = nprobe
+//            2) rows regrouped by list (stable by original row, each list padded to 256 rows);
+//               every list becomes workgroups of <= 256 of the queries that probe it: the list's
+//               rows are streamed from HBM ONCE for all of them (HBM-bound: bytes = list rows x
+//               ld x 2 per workgroup), scored on MFMA and filtered by the same in-kernel top-k
+//            3) per query the nprobe candidate sets are merged by (score desc, original row asc)
+//   The (list -> queries) regrouping of step 2 runs on the host from the D2H'd probe table.
+#include "common.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace mrag {
+
+struct IvfIndex : Object {
+  int dim = 0, ld = 0, nlist = 0, metric = 0, dtype = MRAG_F16;
+  bool has_centroids = false;
+  int64_t n = 0, cap = 0, id_base = 0;
+  uint16_t* cen = nullptr;        // [round256(nlist)][ld]
+  uint16_t* raw = nullptr;        // [cap][ld] rows in arrival order
+  int32_t* assign = nullptr;      // [cap]
+  // regrouped storage (rebuilt lazily)
+  bool dirty = true;
+  uint16_t* sorted = nullptr;     // [n_sorted][ld]
+  int64_t* row_ids = nullptr;     // [n_sorted] original row or -1
+  int64_t n_sorted = 0;
+  std::vector<int> list_tile_lo, list_count;
+  DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
+  ~IvfIndex() override {
+    for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts}) b->release();
+  }
+};
+
+static size_t esize(int dt) { return dt == MRAG_F32 ? 4 : dt == MRAG_F64 ? 8 : (dt == MRAG_F16 || dt == MRAG_BF16) ? 2 : 0; }
+
+__global__ void gather_rows_kernel(const uint16_t* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int ld,
+                                   uint16_t* __restrict__ dst) {
+  // one wave per destination row; idx < 0 -> zero row
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int64_t s = idx[r];
+  const uint4* sp = (const uint4*)(src + (size_t)(s < 0 ? 0 : s) * ld);
+  uint4* dp = (uint4*)(dst + (size_t)r * ld);
+  for (int i = lane; i < ld / 8; i += 64) dp[i] = s < 0 ? make_uint4(0, 0, 0, 0) : sp[i];
+}
+
+__global__ void ids_to_i32_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)ids[i];
+}
+
+template <int BF16>
+__global__ void kmeans_accum_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ a, int64_t n, int ld, int dim,
+                                    float* __restrict__ sums, int* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int64_t c = a[r];
+  if (c < 0) return;
+  const uint16_t* row = x + (size_t)r * ld;
+  for (int i = lane; i < dim; i += 64) {
+    float v;
+    if (BF16) v = __uint_as_float((uint32_t)row[i] << 16);
+    else { _Float16 h; __builtin_memcpy(&h, &row[i], 2); v = (float)h; }
+    atomicAdd(&sums[(size_t)c * dim + i], v);
+  }
+  if (lane == 0) atomicAdd(&cnt[c], 1);
+}
+
+template <int BF16>
+__global__ void kmeans_keep_empty_kernel(const uint16_t* __restrict__ cen, int ld, int dim, int nlist, const int* __restrict__ cnt,
+                                         float* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)nlist * dim) return;
+  const int c = (int)(i / dim), d = (int)(i % dim);
+  if (cnt[c] > 0) return;
+  const uint16_t b = cen[(size_t)c * ld + d];
+  float v;
+  if (BF16) v = __uint_as_float((uint32_t)b << 16);
+  else { _Float16 h; __builtin_memcpy(&h, &b, 2); v = (float)h; }
+  sums[i] = v;   // an empty list keeps its centroid
+}
+
+static int ivf_grow(IvfIndex* ix, int64_t need, hipStream_t stream) {
+  if (need <= ix->cap) return MRAG_OK;
+  int64_t cap = bf_round_rows(std::max<int64_t>(need, ix->cap + ix->cap / 2));
+  uint16_t* nr = nullptr;
+  int32_t* na = nullptr;
+  MRAG_HIP(hipMalloc((void**)&nr, (size_t)cap * ix->ld * 2));
+  MRAG_HIP(hipMalloc((void**)&na, (size_t)cap * 4));
+  MRAG_HIP(hipMemsetAsync(nr, 0, (size_t)cap * ix->ld * 2, stream));
+  if (ix->n) {
+    MRAG_HIP(hipMemcpyAsync(nr, ix->raw, (size_t)ix->n * ix->ld * 2, hipMemcpyDeviceToDevice, stream));
+    MRAG_HIP(hipMemcpyAsync(na, ix->assign, (size_t)ix->n * 4, hipMemcpyDeviceToDevice, stream));
+  }
+  MRAG_HIP(hipStreamSynchronize(stream));
+  if (ix->raw) (void)hipFree(ix->raw);
+  if (ix->assign) (void)hipFree(ix->assign);
+  ix->raw = nr; ix->assign = na; ix->cap = cap;
+  return MRAG_OK;
+}
+
+// nearest centroid (k = 1) of prepared rows x [n][ld] (n need not be a multiple of 256: the
+// buffer behind it must be readable up to the next multiple) -> out_ids int64 [n]
+static int ivf_assign_rows(IvfIndex* ix, const uint16_t* x, int64_t n, int64_t* out_ids, float* out_sc, hipStream_t stream) {
+  BfLaunch a;
+  a.corpus = ix->cen; a.queries = x; a.ld = ix->ld; a.dtype = ix->dtype; a.k = 1;
+  a.nq = n; a.n_rows = ix->nlist; a.id_base = 0;
+  a.out_scores = out_sc; a.out_ids = out_ids;
+  a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
+  return bf_launch(a);
+}
+
+// rows (any dtype, host or device) -> prepared storage rows at dst (device), padded buffer rows zeroed by caller
+static int ivf_prepare(IvfIndex* ix, const void* rows, int64_t n, int src_dtype, int normalize, int is_device, uint16_t* dst,
+                       hipStream_t stream) {
+  const void* src = rows;
+  if (!is_device) {
+    const size_t bytes = (size_t)n * ix->dim * esize(src_dtype);
+    MRAG_TRY(ix->stage_in.ensure(bytes));
+    MRAG_HIP(hipMemcpyAsync(ix->stage_in.p, rows, bytes, hipMemcpyHostToDevice, stream));
+    src = ix->stage_in.p;
+  }
+  return launch_prep_rows(src, src_dtype, n, ix->dim, dst, ix->ld, ix->dtype, normalize && ix->metric == MRAG_METRIC_COSINE, stream);
+}
+
+static uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// regroup rows by list: stable by original row, each list padded to a multiple of 256 rows
+static int ivf_finalize(IvfIndex* ix, hipStream_t stream) {
+  if (!ix->dirty) return MRAG_OK;
+  const int64_t n = ix->n;
+  std::vector<int32_t> a((size_t)n);
+  if (n) MRAG_HIP(hipMemcpyAsync(a.data(), ix->assign, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  ix->list_count.assign(ix->nlist, 0);
+  for (int64_t i = 0; i < n; ++i) ix->list_count[a[i]]++;
+  ix->list_tile_lo.assign(ix->nlist, 0);
+  int64_t tiles = 0;
+  for (int l = 0; l < ix->nlist; ++l) { ix->list_tile_lo[l] = (int)tiles; tiles += (ix->list_count[l] + 255) / 256; }
+  const int64_t ns = std::max<int64_t>(tiles, 1) * 256;
+  std::vector<int64_t> perm((size_t)ns, -1);
+  std::vector<int64_t> cur(ix->nlist);
+  for (int l = 0; l < ix->nlist; ++l) cur[l] = (int64_t)ix->list_tile_lo[l] * 256;
+  for (int64_t i = 0; i < n; ++i) perm[cur[a[i]]++] = i;
+  if (ix->sorted) (void)hipFree(ix->sorted);
+  if (ix->row_ids) (void)hipFree(ix->row_ids);
+  ix->sorted = nullptr; ix->row_ids = nullptr;
+  MRAG_HIP(hipMalloc((void**)&ix->sorted, (size_t)ns * ix->ld * 2));
+  MRAG_HIP(hipMalloc((void**)&ix->row_ids, (size_t)ns * 8));
+  MRAG_HIP(hipMemcpyAsync(ix->row_ids, perm.data(), (size_t)ns * 8, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, stream, ix->raw ? ix->raw : ix->sorted, ix->row_ids, ns, ix->ld, ix->sorted);
+  MRAG_HIP(hipGetLastError());
+  MRAG_HIP(hipStreamSynchronize(stream));
+  ix->n_sorted = ns;
+  ix->dirty = false;
+  return MRAG_OK;
+}
+
+}  // namespace mrag
+
+using namespace mrag;
+
+extern "C" {
+
+int mrag_ivf_create(int dim, int nlist, int metric, int storage_dtype, int device, mrag_handle* out) {
+  if (!out) return fail(MRAG_ERR_INVALID, "out is NULL");
+  if (dim <= 0 || dim > 8192) return fail(MRAG_ERR_INVALID, "dim %d out of range", dim);
+  if (nlist <= 0 || nlist > (1 << 20)) return fail(MRAG_ERR_INVALID, "nlist %d out of range", nlist);
+  if (storage_dtype != MRAG_F16 && storage_dtype != MRAG_BF16) return fail(MRAG_ERR_INVALID, "storage dtype must be fp16 or bf16");
+  MRAG_TRY(use_device(device));
+  IvfIndex* ix = new IvfIndex();
+  ix->kind = KIND_IVF; ix->device = device; ix->dim = dim; ix->ld = (int)round_up(dim, 64);
+  ix->nlist = nlist; ix->metric = metric; ix->dtype = storage_dtype;
+  const size_t cb = (size_t)bf_round_rows(nlist) * ix->ld * 2;
+  if (hipMalloc((void**)&ix->cen, cb) != hipSuccess) { delete ix; return fail(MRAG_ERR_OOM, "centroid allocation failed"); }
+  (void)hipMemset(ix->cen, 0, cb);
+  *out = register_object(ix);
+  return MRAG_OK;
+}
+
+int mrag_ivf_destroy(mrag_handle h) {
+  Object* o = take(h, KIND_IVF);
+  if (!o) return MRAG_ERR_INVALID;
+  (void)hipSetDevice(o->device);
+  (void)hipDeviceSynchronize();
+  delete o;
+  return MRAG_OK;
+}
+
+int mrag_ivf_set_centroids(mrag_handle h, const void* centroids, int src_dtype, int normalize, int is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!centroids || !esize(src_dtype)) return fail(MRAG_ERR_INVALID, "bad centroid buffer / dtype");
+  if (ix->n) return fail(MRAG_ERR_INVALID, "centroids cannot change after rows were added");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  MRAG_TRY(ivf_prepare(ix, centroids, ix->nlist, src_dtype, normalize, is_device, ix->cen, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  ix->has_centroids = true;
+  return MRAG_OK;
+}
+
+int mrag_ivf_get_centroids(mrag_handle h, float* out, int out_is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!out) return fail(MRAG_ERR_INVALID, "out is NULL");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<uint16_t> hc((size_t)ix->nlist * ix->ld);
+  MRAG_HIP(hipMemcpyAsync(hc.data(), ix->cen, hc.size() * 2, hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  std::vector<float> f((size_t)ix->nlist * ix->dim);
+  for (int r = 0; r < ix->nlist; ++r)
+    for (int c = 0; c < ix->dim; ++c) {
+      const uint16_t b = hc[(size_t)r * ix->ld + c];
+      float v;
+      if (ix->dtype == MRAG_BF16) { uint32_t u = (uint32_t)b << 16; memcpy(&v, &u, 4); }
+      else { _Float16 hh; memcpy(&hh, &b, 2); v = (float)hh; }
+      f[(size_t)r * ix->dim + c] = v;
+    }
+  if (out_is_device) MRAG_HIP(hipMemcpy(out, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  else memcpy(out, f.data(), f.size() * 4);
+  return MRAG_OK;
+}
+
+int mrag_ivf_train(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize, int rows_is_device, int iters,
+                   uint64_t seed, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!rows || !esize(src_dtype)) return fail(MRAG_ERR_INVALID, "bad rows buffer / dtype");
+  if (n < ix->nlist) return fail(MRAG_ERR_INVALID, "need at least nlist = %d training rows, got %lld", ix->nlist, (long long)n);
+  if (ix->n) return fail(MRAG_ERR_INVALID, "train before adding rows");
+  if (iters < 0) return fail(MRAG_ERR_INVALID, "iters < 0");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t npad = bf_round_rows(n);
+  DevBuf x;
+  MRAG_TRY(x.ensure((size_t)npad * ix->ld * 2));
+  MRAG_HIP(hipMemsetAsync(x.p, 0, (size_t)npad * ix->ld * 2, stream));
+  int st = ivf_prepare(ix, rows, n, src_dtype, normalize, rows_is_device, (uint16_t*)x.p, stream);
+  if (st != MRAG_OK) { x.release(); return st; }
+  // init: nlist distinct rows (Floyd's sampling from splitmix64(seed)), in ascending row order
+  std::vector<int64_t> pick;
+  {
+    std::vector<int64_t> chosen;
+    uint64_t s = seed;
+    for (int64_t j = n - ix->nlist; j < n; ++j) {
+      int64_t t = (int64_t)(splitmix64(s) % (uint64_t)(j + 1));
+      if (std::find(chosen.begin(), chosen.end(), t) != chosen.end()) t = j;
+      chosen.push_back(t);
+    }
+    std::sort(chosen.begin(), chosen.end());
+    pick = chosen;
+  }
+  DevBuf dpick, ids, sc;
+  st = dpick.ensure((size_t)ix->nlist * 8);
+  if (st == MRAG_OK) st = ids.ensure((size_t)n * 8);
+  if (st == MRAG_OK) st = sc.ensure((size_t)n * 4);
+  if (st == MRAG_OK) st = ix->sums.ensure((size_t)ix->nlist * ix->dim * 4);
+  if (st == MRAG_OK) st = ix->cnts.ensure((size_t)ix->nlist * 4);
+  auto cleanup = [&]() { x.release(); dpick.release(); ids.release(); sc.release(); };
+  if (st != MRAG_OK) { cleanup(); return st; }
+  hipError_t e = hipMemcpyAsync(dpick.p, pick.data(), (size_t)ix->nlist * 8, hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) { cleanup(); return fail(MRAG_ERR_HIP, "H2D failed"); }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ix->nlist + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)x.p,
+                     (const int64_t*)dpick.p, (int64_t)ix->nlist, ix->ld, ix->cen);
+  (void)hipStreamSynchronize(stream);
+  for (int it = 0; it < iters; ++it) {
+    st = ivf_assign_rows(ix, (const uint16_t*)x.p, n, (int64_t*)ids.p, (float*)sc.p, stream);
+    if (st != MRAG_OK) { cleanup(); return st; }
+    (void)hipMemsetAsync(ix->sums.p, 0, (size_t)ix->nlist * ix->dim * 4, stream);
+    (void)hipMemsetAsync(ix->cnts.p, 0, (size_t)ix->nlist * 4, stream);
+    const dim3 g((unsigned)((n + 3) / 4)), b(256);
+    const dim3 g2((unsigned)(((int64_t)ix->nlist * ix->dim + 255) / 256));
+    if (ix->dtype == MRAG_BF16) {
+      hipLaunchKernelGGL((kmeans_accum_kernel<1>), g, b, 0, stream, (const uint16_t*)x.p, (const int64_t*)ids.p, n, ix->ld, ix->dim, (float*)ix->sums.p, (int*)ix->cnts.p);
+      hipLaunchKernelGGL((kmeans_keep_empty_kernel<1>), g2, b, 0, stream, ix->cen, ix->ld, ix->dim, ix->nlist, (const int*)ix->cnts.p, (float*)ix->sums.p);
+    } else {
+      hipLaunchKernelGGL((kmeans_accum_kernel<0>), g, b, 0, stream, (const uint16_t*)x.p, (const int64_t*)ids.p, n, ix->ld, ix->dim, (float*)ix->sums.p, (int*)ix->cnts.p);
+      hipLaunchKernelGGL((kmeans_keep_empty_kernel<0>), g2, b, 0, stream, ix->cen, ix->ld, ix->dim, ix->nlist, (const int*)ix->cnts.p, (float*)ix->sums.p);
+    }
+    st = launch_prep_rows(ix->sums.p, MRAG_F32, ix->nlist, ix->dim, ix->cen, ix->ld, ix->dtype, ix->metric == MRAG_METRIC_COSINE, stream);
+    if (st != MRAG_OK) { cleanup(); return st; }
+  }
+  e = hipStreamSynchronize(stream);
+  cleanup();
+  if (e != hipSuccess) return fail(MRAG_ERR_HIP, "k-means failed: %s", hipGetErrorString(e));
+  ix->has_centroids = true;
+  return MRAG_OK;
+}
+
+int mrag_ivf_add(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize, int rows_is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (n < 0) return fail(MRAG_ERR_INVALID, "n < 0");
+  if (n == 0) return MRAG_OK;
+  if (!rows || !esize(src_dtype)) return fail(MRAG_ERR_INVALID, "bad rows buffer / dtype");
+  if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "train or set centroids before adding rows");
+  if (ix->n + n > 0x7FFFFF00ll) return fail(MRAG_ERR_UNSUPPORTED, "more than 2^31 rows per index; shard the corpus");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  MRAG_TRY(ivf_grow(ix, ix->n + n, stream));
+  uint16_t* dst = ix->raw + (size_t)ix->n * ix->ld;
+  MRAG_TRY(ivf_prepare(ix, rows, n, src_dtype, normalize, rows_is_device, dst, stream));
+  MRAG_TRY(ix->tmp_id.ensure((size_t)n * 8));
+  MRAG_TRY(ix->tmp_sc.ensure((size_t)n * 4));
+  // (the raw buffer is a multiple of 256 rows and zero beyond n: safe to read as padded queries)
+  MRAG_TRY(ivf_assign_rows(ix, dst, n, (int64_t*)ix->tmp_id.p, (float*)ix->tmp_sc.p, stream));
+  hipLaunchKernelGGL(ids_to_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, n, ix->assign + ix->n);
+  MRAG_HIP(hipGetLastError());
+  MRAG_HIP(hipStreamSynchronize(stream));
+  ix->n += n;
+  ix->dirty = true;
+  return MRAG_OK;
+}
+
+int mrag_ivf_size(mrag_handle h, int64_t* out_rows) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!out_rows) return fail(MRAG_ERR_INVALID, "out_rows is NULL");
+  *out_rows = ix->n;
+  return MRAG_OK;
+}
+
+int mrag_ivf_set_id_base(mrag_handle h, int64_t id_base) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  ix->id_base = id_base;
+  return MRAG_OK;
+}
+
+int mrag_ivf_get_assignments(mrag_handle h, int32_t* out, int out_is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!out && ix->n) return fail(MRAG_ERR_INVALID, "out is NULL");
+  if (!ix->n) return MRAG_OK;
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  MRAG_HIP(hipMemcpyAsync(out, ix->assign, (size_t)ix->n * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  return MRAG_OK;
+}
+
+int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize, int queries_is_device, int nprobe,
+                    int k, float* out_scores, int64_t* out_ids, int out_is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (nq < 0 || k <= 0 || nprobe <= 0) return fail(MRAG_ERR_INVALID, "bad nq / k / nprobe");
+  if (k > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the fused top-k limit %d", k, bf_max_k());
+  nprobe = std::min(nprobe, ix->nlist);
+  if (nprobe > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "nprobe = %d exceeds %d", nprobe, bf_max_k());
+  if (nq == 0) return MRAG_OK;
+  if (!queries || !out_scores || !out_ids || !esize(q_dtype)) return fail(MRAG_ERR_INVALID, "bad buffer / dtype");
+  if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "index has no centroids");
+  if (nq > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF call; batch the queries");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  MRAG_TRY(ivf_finalize(ix, stream));
+
+  float* d_sc = out_scores;
+  int64_t* d_id = out_ids;
+  if (!out_is_device) {
+    MRAG_TRY(ix->out_sc.ensure((size_t)nq * k * 4));
+    MRAG_TRY(ix->out_id.ensure((size_t)nq * k * 8));
+    d_sc = (float*)ix->out_sc.p;
+    d_id = (int64_t*)ix->out_id.p;
+  }
+  // 1) queries -> storage dtype; probe lists
+  const int64_t nq_pad = bf_round_rows(nq);
+  MRAG_TRY(ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2));
+  MRAG_HIP(hipMemsetAsync(ix->qbuf.p, 0, (size_t)nq_pad * ix->ld * 2, stream));
+  MRAG_TRY(ivf_prepare(ix, queries, nq, q_dtype, normalize, queries_is_device, (uint16_t*)ix->qbuf.p, stream));
+  MRAG_TRY(ix->tmp_id.ensure((size_t)nq * nprobe * 8));
+  MRAG_TRY(ix->tmp_sc.ensure((size_t)nq * nprobe * 4));
+  {
+    BfLaunch a;
+    a.corpus = ix->cen; a.queries = (const uint16_t*)ix->qbuf.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = nprobe;
+    a.nq = nq; a.n_rows = ix->nlist;
+    a.out_scores = (float*)ix->tmp_sc.p; a.out_ids = (int64_t*)ix->tmp_id.p;
+    a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
+    MRAG_TRY(bf_launch(a));
+  }
+  std::vector<int64_t> probes((size_t)nq * nprobe);
+  MRAG_HIP(hipMemcpyAsync(probes.data(), ix->tmp_id.p, probes.size() * 8, hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  // 2) host: list -> the queries that probe it, cut into workgroups of <= 256 queries
+  std::vector<std::vector<int>> by_list(ix->nlist);
+  for (int64_t q = 0; q < nq; ++q)
+    for (int pi = 0; pi < nprobe; ++pi) {
+      const int64_t l = probes[(size_t)q * nprobe + pi];
+      if (l >= 0 && ix->list_count[l] > 0) by_list[l].push_back((int)q);
+    }
+  std::vector<int> desc;            // 8 ints per workgroup
+  std::vector<int64_t> gq;          // query row feeding each of the 256 slots of every workgroup (-1 = zero row)
+  std::vector<int> ploc((size_t)nq * nprobe * 2, -1);
+  std::vector<int> fill_pi((size_t)nq, 0);
+  // (pair_loc is indexed by the query's probe ORDER; recover it while walking the lists)
+  std::vector<int> probe_slot((size_t)nq * nprobe, -1);
+  int n_wg = 0;
+  for (int l = 0; l < ix->nlist; ++l) {
+    const auto& qs = by_list[l];
+    for (size_t c0 = 0; c0 < qs.size(); c0 += 256) {
+      const int cnt = (int)std::min<size_t>(256, qs.size() - c0);
+      desc.insert(desc.end(), {n_wg * 256, cnt, ix->list_tile_lo[l], ix->list_tile_lo[l] + (ix->list_count[l] + 255) / 256,
+                               ix->list_tile_lo[l] * 256 + ix->list_count[l], 0, 0, 0});
+      for (int i = 0; i < 256; ++i) gq.push_back(i < cnt ? (int64_t)qs[c0 + i] : -1);
+      for (int i = 0; i < cnt; ++i) {
+        const int q = qs[c0 + i];
+        int pi = 0;
+        while (probes[(size_t)q * nprobe + pi] != l) ++pi;          // nprobe <= 64
+        ploc[((size_t)q * nprobe + pi) * 2] = n_wg;
+        ploc[((size_t)q * nprobe + pi) * 2 + 1] = i;
+      }
+      ++n_wg;
+    }
+  }
+  for (size_t i = 0; i < ploc.size(); i += 2) if (ploc[i] < 0) ploc[i + 1] = 0;
+  // 3) gather queries per workgroup, scan the lists, merge
+  MRAG_TRY(ix->ploc.ensure(ploc.size() * 4));
+  MRAG_HIP(hipMemcpyAsync(ix->ploc.p, ploc.data(), ploc.size() * 4, hipMemcpyHostToDevice, stream));
+  if (n_wg) {
+    MRAG_TRY(ix->desc.ensure(desc.size() * 4));
+    MRAG_TRY(ix->gq.ensure(gq.size() * 8));
+    MRAG_TRY(ix->qg.ensure((size_t)n_wg * 256 * ix->ld * 2));
+    MRAG_HIP(hipMemcpyAsync(ix->desc.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, stream));
+    MRAG_HIP(hipMemcpyAsync(ix->gq.p, gq.data(), gq.size() * 8, hipMemcpyHostToDevice, stream));
+    const int64_t ng = (int64_t)n_wg * 256;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)ix->qbuf.p,
+                       (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p);
+    MRAG_HIP(hipGetLastError());
+  }
+  {
+    BfLaunch a;
+    a.corpus = ix->sorted; a.queries = (const uint16_t*)ix->qg.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = k;
+    a.nq = nq;
+    static const int dummy_desc = 0;
+    a.wg_desc = n_wg ? (const int*)ix->desc.p : &dummy_desc; a.n_wg = n_wg;
+    a.pair_loc = ix->ploc.p; a.nprobe = nprobe; a.row_ids = ix->row_ids;
+    a.id_base = ix->id_base;
+    a.out_scores = d_sc; a.out_ids = d_id;
+    a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
+    MRAG_TRY(bf_launch(a));
+  }
+  if (!out_is_device) {
+    MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+    MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
+  }
+  MRAG_HIP(hipStreamSynchronize(stream));   // host vectors above must outlive the async copies
+  return MRAG_OK;
+}
+
+}  // extern "C"

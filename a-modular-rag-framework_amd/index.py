@@ -169,3 +169,71 @@ def topk_merge(scores: np.ndarray, ids: np.ndarray, nthreads: int = 0) -> Tuple[
     N.check(N.load().mrag_topk_merge(s.ctypes.data, i.ctypes.data, nparts, nq, k, os_.ctypes.data,
                                      oi.ctypes.data, int(nthreads)))
     return os_, oi
+
+
+class IVFFlatIndex:
+    """IVF-flat index on one GPU (BASELINE.json config 5): nlist spherical-k-means lists, every
+    search probes the ``nprobe`` best lists and scans them exactly.  Same id / tie-break
+    conventions as :class:`DenseIndex`."""
+
+    def __init__(self, dim: int, nlist: int, metric: str = "cosine", dtype: str = "f16", device: int = 0):
+        self._lib = N.load()
+        self.dim, self.nlist, self.metric, self.dtype, self.device = int(dim), int(nlist), metric, dtype, int(device)
+        h = C.c_uint64(0)
+        N.check(self._lib.mrag_ivf_create(self.dim, self.nlist, N.METRIC_COSINE if metric == "cosine" else N.METRIC_IP,
+                                          N.MRAG_F16 if dtype == "f16" else N.MRAG_BF16, self.device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mrag_ivf_destroy(self._h)
+            self._h = C.c_uint64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = C.c_int64(0)
+        N.check(self._lib.mrag_ivf_size(self._h, C.byref(n)))
+        return n.value
+
+    def _norm(self, normalize):
+        return int(bool(self.metric == "cosine" if normalize is None else normalize))
+
+    def train(self, rows, iters: int = 10, seed: int = 0, normalize: Optional[bool] = None):
+        keep, ptr, n, dt, is_dev = _as_buffer(rows, self.dim)
+        N.check(self._lib.mrag_ivf_train(self._h, ptr, n, dt, self._norm(normalize), is_dev, int(iters), int(seed), None))
+
+    def set_centroids(self, centroids, normalize: Optional[bool] = None):
+        keep, ptr, n, dt, is_dev = _as_buffer(centroids, self.dim)
+        if n != self.nlist:
+            raise ValueError(f"expected {self.nlist} centroids, got {n}")
+        N.check(self._lib.mrag_ivf_set_centroids(self._h, ptr, dt, self._norm(normalize), is_dev, None))
+
+    def centroids(self) -> np.ndarray:
+        out = np.empty((self.nlist, self.dim), dtype=np.float32)
+        N.check(self._lib.mrag_ivf_get_centroids(self._h, out.ctypes.data, 0, None))
+        return out
+
+    def add(self, rows, normalize: Optional[bool] = None):
+        keep, ptr, n, dt, is_dev = _as_buffer(rows, self.dim)
+        N.check(self._lib.mrag_ivf_add(self._h, ptr, n, dt, self._norm(normalize), is_dev, None))
+
+    def set_id_base(self, base: int):
+        N.check(self._lib.mrag_ivf_set_id_base(self._h, int(base)))
+
+    def assignments(self) -> np.ndarray:
+        out = np.empty(len(self), dtype=np.int32)
+        N.check(self._lib.mrag_ivf_get_assignments(self._h, out.ctypes.data, 0, None))
+        return out
+
+    def search(self, queries, k: int, nprobe: int, normalize: Optional[bool] = None) -> Tuple[np.ndarray, np.ndarray]:
+        keep, ptr, nq, dt, is_dev = _as_buffer(queries, self.dim)
+        sc = np.empty((nq, k), dtype=np.float32)
+        ids = np.empty((nq, k), dtype=np.int64)
+        N.check(self._lib.mrag_ivf_search(self._h, ptr, nq, dt, self._norm(normalize), is_dev, int(nprobe), int(k),
+                                          sc.ctypes.data, ids.ctypes.data, 0, None))
+        return sc, ids

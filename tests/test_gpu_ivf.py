@@ -1,0 +1,89 @@
+"""GPU parity of IVF-flat (BASELINE config 5 shape family).  The reference ships no IVF index:
+parity is UNPINNED by the reference and checked against the oracle's ivf_search on identical
+centroids + assignments, and against brute force for recall."""
+import numpy as np
+import pytest
+
+from oracle import dense_search as ds
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, nq, d, seed):
+    rows, qs = ds.make_clustered(n, nq, d, seed, n_centroids=64)
+    return ds.normalize_round(rows), ds.normalize_round(qs)
+
+
+def test_assignment_and_search_match_oracle_on_given_centroids():
+    from mrag_amd.index import IVFFlatIndex
+    n, nq, d, nlist, nprobe, k = 20000, 300, 128, 64, 8, 10
+    c16, q16 = _data(n, nq, d, 7)
+    cen = ds.kmeans_spherical(c16, nlist, 4, seed=3)
+    ix = IVFFlatIndex(d, nlist)
+    ix.set_centroids(cen, normalize=False)
+    assert np.array_equal(ix.centroids().astype(np.float16), cen)
+    for lo in range(0, n, 7000):                            # incremental adds
+        ix.add(c16[lo:lo + 7000], normalize=False)
+    assert len(ix) == n
+    a_ref = ds.ivf_assign(c16, cen)
+    a_gpu = ix.assignments()
+    # assignment = argmax in fp32-accumulated MFMA vs fp64: only fp-near-ties may differ
+    cs = np.sort(c16.astype(np.float64) @ cen.astype(np.float64).T, axis=1)
+    near = (cs[:, -1] - cs[:, -2]) < 1e-5
+    assert (a_gpu[~near] == a_ref[~near]).all() and near.mean() < 0.01
+    sc, ids = ix.search(q16, k, nprobe, normalize=False)
+    rv, ri = ds.ivf_search(q16, c16, cen, a_gpu.astype(np.int64), nprobe, k)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
+    # a query whose nprobe-th and (nprobe+1)-th centroid scores tie within fp32 may probe another list
+    assert bad <= 0.002 * nq * k, (strict, bad)
+    bv, bi = ds.brute_force_topk(q16, c16, k)
+    assert ds.recall_at_k(ids, bi) > 0.8
+    # probing every list == brute force
+    sc_all, ids_all = ix.search(q16, k, nlist, normalize=False)
+    np.testing.assert_allclose(sc_all, bv, rtol=0, atol=1e-5)
+    s2, b2 = ds.gap_aware_id_match(ids_all, sc_all, bi, bv, tol=1e-5)
+    assert b2 == 0 and ds.recall_at_k(ids_all, bi) >= 0.999
+
+
+def test_train_on_device_gives_useful_lists():
+    from mrag_amd.index import IVFFlatIndex
+    n, nq, d, nlist, k = 30000, 200, 64, 128, 10
+    c16, q16 = _data(n, nq, d, 11)
+    ix = IVFFlatIndex(d, nlist)
+    ix.train(c16, iters=8, seed=5, normalize=False)
+    cen = ix.centroids()
+    np.testing.assert_allclose(np.linalg.norm(cen, axis=1), 1.0, atol=2e-3)
+    ix2 = IVFFlatIndex(d, nlist)
+    ix2.train(c16, iters=8, seed=5, normalize=False)        # seeded: reproducible up to float-atomic order
+    assert np.abs(ix2.centroids() - cen).max() < 5e-3
+    ix.add(c16, normalize=False)
+    ix.set_id_base(5_000_000)
+    counts = np.bincount(ix.assignments(), minlength=nlist)
+    assert counts.sum() == n and (counts > 0).mean() > 0.9
+    bv, bi = ds.brute_force_topk(q16, c16, k)
+    sc, ids = ix.search(q16, k, 16, normalize=False)
+    assert (ids[ids >= 0] >= 5_000_000).all()
+    assert ds.recall_at_k(ids - 5_000_000, bi) > 0.85
+    # found ids carry their exact scores
+    got = {(i, int(j)): s for i in range(nq) for j, s in zip(ids[i] - 5_000_000, sc[i]) if j >= 0}
+    full = q16.astype(np.float64) @ c16.astype(np.float64).T
+    for (i, j), s in list(got.items())[:500]:
+        assert abs(full[i, j] - s) < 1e-5
+
+
+def test_ivf_edge_cases():
+    from mrag_amd.index import IVFFlatIndex
+    from mrag_amd._native import MragError
+    d = 32
+    ix = IVFFlatIndex(d, 4)
+    with pytest.raises(MragError):
+        ix.add(np.zeros((3, d), np.float32))               # no centroids yet
+    cen = ds.normalize_round(ds.make_gaussian(4, d, 1))
+    ix.set_centroids(cen, normalize=False)
+    sc, ids = ix.search(ds.normalize_round(ds.make_gaussian(3, d, 2)), 5, 2, normalize=False)   # empty index
+    assert (ids == -1).all() and np.isneginf(sc).all()
+    rows = ds.normalize_round(ds.make_gaussian(7, d, 3))
+    ix.add(rows, normalize=False)
+    sc, ids = ix.search(rows[:2], 10, 4, normalize=False)  # k > n
+    assert (ids[:, 7:] == -1).all() and (ids[:, 0] == [0, 1]).all()
