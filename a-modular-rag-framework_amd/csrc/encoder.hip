@@ -1,0 +1,643 @@
+// K6: BERT-family sentence-encoder forward (MiniLM-L6 / bge-base shapes) -- fills the
+// LLMProvider.embed slot of the reference (app/core/providers/base.py:6, called from
+// app/core/llm_router.py:115).  The reference itself contains no encoder; the architecture
+// follows HF BertModel (embeddings + LN, L x {MHA, erf-GELU FFN, post-LN residuals}), pooling
+// (mean over the mask, or CLS) and L2 normalisation as in sentence-transformers.
+//
+// Kernels (fp16 or bf16 activations/weights, fp32 accumulation and fp32 LN/softmax/GELU math)
+//   enc_embed_ln_kernel   gather word + position + type rows, LayerNorm, one wave per token
+//   enc_gemm_kernel<EPI>  C = A . W^T + bias on MFMA 16x16x32: 128 x 128 x 64 tiles, 4 waves,
+//                         LDS-DMA staged, XOR-swizzled 128-B rows (same scheme as K2); epilogues
+//                         fused: bias | bias + erf-GELU | bias + residual
+//   enc_attention_kernel  per (batch, head, 64 query rows): flash-style loop over 64-key blocks,
+//                         QK^T and PV on MFMA, online softmax in the accumulator layout
+//                         (row = (lane>>4)*4+j, reduced over the 16 lanes of a row by shuffles),
+//                         P staged through LDS as the next MFMA's A operand, V transposed on store
+//   enc_ln_kernel         LayerNorm (the residual add is in the GEMM epilogue)
+//   enc_pool_kernel       masked mean or CLS, optional L2 normalisation, fp32 out
+// MFMA-bound (~170 MFLOP/token for bge-base); LN/softmax/GELU ride in epilogues.
+#include "common.h"
+
+#include <math.h>
+#include <map>
+#include <string>
+
+namespace mrag {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+template <int DT> struct EMfma;
+template <> struct EMfma<MRAG_F16> {
+  typedef f16x8 frag;
+  typedef _Float16 elem;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct EMfma<MRAG_BF16> {
+  typedef bf16x8 frag;
+  typedef __bf16 elem;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------ embeddings + LayerNorm
+template <typename E>
+__global__ __launch_bounds__(256) void enc_embed_ln_kernel(const int32_t* __restrict__ ids, int64_t n_tok, int S, int H, int vocab,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0, const float* __restrict__ g,
+                                                           const float* __restrict__ b, float eps, E* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tok) return;
+  int id = ids[tok];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int s = (int)(tok % S);
+  const float* w = word + (size_t)id * H;
+  const float* p = pos + (size_t)s * H;
+  float sum = 0.f, sq = 0.f;
+  for (int i = lane; i < H; i += 64) {
+    const float x = w[i] + p[i] + type0[i];
+    sum += x;
+  }
+  sum = wave_sum(sum);
+  const float mean = sum / H;
+  for (int i = lane; i < H; i += 64) {
+    const float x = w[i] + p[i] + type0[i] - mean;
+    sq += x * x;
+  }
+  sq = wave_sum(sq);
+  const float rstd = 1.0f / sqrtf(sq / H + eps);
+  for (int i = lane; i < H; i += 64) {
+    const float x = w[i] + p[i] + type0[i];
+    out[(size_t)tok * H + i] = (E)((x - mean) * rstd * g[i] + b[i]);
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(256) void enc_ln_kernel(const E* __restrict__ x, int64_t n_tok, int H, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps, E* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tok) return;
+  const E* r = x + (size_t)tok * H;
+  float sum = 0.f, sq = 0.f;
+  for (int i = lane; i < H; i += 64) sum += (float)r[i];
+  sum = wave_sum(sum);
+  const float mean = sum / H;
+  for (int i = lane; i < H; i += 64) {
+    const float d = (float)r[i] - mean;
+    sq += d * d;
+  }
+  sq = wave_sum(sq);
+  const float rstd = 1.0f / sqrtf(sq / H + eps);
+  for (int i = lane; i < H; i += 64) out[(size_t)tok * H + i] = (E)(((float)r[i] - mean) * rstd * g[i] + b[i]);
+}
+
+// ------------------------------------------------------------------ GEMM with fused epilogues
+constexpr int GM = 128, GN = 128, GK = 64, GTHR = 256;
+constexpr int G_A_BYTES = GM * GK * 2;             // 16 KiB
+constexpr int G_STAGE = (GM + GN) * GK * 2;        // 32 KiB
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+// A [M_pad][K], W [N_pad][K] (both K-contiguous, K % 64 == 0, M_pad % 128 == 0, N_pad % 128 == 0),
+// C [M_pad][N] (only columns < N are written), R same shape as C.
+template <int DT, int EPI>
+__global__ __launch_bounds__(GTHR) void enc_gemm_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                        const float* __restrict__ bias, const uint16_t* __restrict__ R,
+                                                        uint16_t* __restrict__ C, int M_pad, int N, int K, int n_tiles_n) {
+  typedef typename EMfma<DT>::frag frag;
+  typedef typename EMfma<DT>::elem elem;
+  __shared__ __attribute__((aligned(16))) char sm[2 * G_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  // XCD-aware: consecutive blocks of one XCD walk N first so they share the A row panel in L2
+  const int nblk = gridDim.x, b = blockIdx.x;
+  const int lin = (nblk % 8 == 0) ? (b & 7) * (nblk / 8) + (b >> 3) : b;   // bijective only when nblk % 8 == 0
+  const int tm = lin / n_tiles_n, tn = lin - tm * n_tiles_n;
+
+  int src_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (4 * w + i) * 8 + (lane >> 3);
+    const int kc = (lane & 7) ^ ((r >> 1) & 7);
+    src_off[i] = r * K + kc * 8;
+  }
+  const uint16_t* a0 = A + (size_t)tm * GM * K;
+  const uint16_t* w0 = W + (size_t)tn * GN * K;
+  auto stage = [&](int kk, int buf) {
+    char* la = sm + buf * G_STAGE + (4 * w) * 1024;
+    char* lb = la + G_A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr)(a0 + kk * GK + src_off[i]), (lds_vptr)(la + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_vptr)(w0 + kk * GK + src_off[i]), (lds_vptr)(lb + i * 1024), 16, 0, 0);
+  };
+  const int frow = lane & 15, fsw = frow >> 1;
+  const int a_rd = (wm * 64 + frow) * 128, b_rd = G_A_BYTES + (wn * 64 + frow) * 128;
+  const int ph0 = ((lane >> 4) ^ fsw) * 16;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = K / GK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kk = 0; kk < nk; ++kk) {
+    const int buf = kk & 1;
+    if (kk + 1 < nk) stage(kk + 1, buf ^ 1);
+    const char* sb = sm + buf * G_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ph = ks ? (ph0 ^ 64) : ph0;
+      frag af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const frag*)(sb + a_rd + i * 2048 + ph);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *(const frag*)(sb + b_rd + j * 2048 + ph);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = EMfma<DT>::run(af[i], bf[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // epilogue: C[row][col], row = tm*128 + wm*64 + i*16 + (lane>>4)*4 + r, col = tn*128 + wn*64 + j*16 + (lane&15)
+  const int row_b = tm * GM + wm * 64 + (lane >> 4) * 4;
+  const int col_b = tn * GN + wn * 64 + (lane & 15);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col_b + j * 16;
+    if (col >= N) continue;
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = (size_t)(row_b + i * 16 + r) * N + col;
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        if (EPI == EPI_RESID) { elem rr; __builtin_memcpy(&rr, &R[off], 2); v += (float)rr; }
+        const elem o = (elem)v;
+        __builtin_memcpy(&C[off], &o, 2);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ attention
+// QKV [M_pad][3H] (q | k | v per token), mask [B][S] (1 = token), out [M_pad][H].
+// grid = B * heads * ceil(S/64); 256 threads: wave w owns query rows 16w..16w+15 of the block.
+template <int DT, int DH>
+__global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                            uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
+  typedef typename EMfma<DT>::frag frag;
+  typedef typename EMfma<DT>::elem elem;
+  constexpr int KB = 64;                       // keys per block
+  constexpr int NK = DH / 32;                  // k-steps of the QK^T contraction
+  constexpr int ND = DH / 16;                  // 16-column groups of the output
+  __shared__ __attribute__((aligned(16))) elem sK[KB][DH + 8];       // [key][dh]   (+8: 16-B pad against bank conflicts)
+  __shared__ __attribute__((aligned(16))) elem sVt[DH][KB + 8];      // [dh][key]
+  __shared__ __attribute__((aligned(16))) elem sP[4][16][KB + 8];    // per wave [q row][key]
+  __shared__ float sBias[KB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nqb = (S + 63) / 64;
+  const int qb = blockIdx.x % nqb;
+  const int hh = (blockIdx.x / nqb) % heads;
+  const int bb = blockIdx.x / (nqb * heads);
+  const size_t ld = (size_t)3 * H;
+  const uint16_t* base = qkv + (size_t)bb * S * ld;
+  const int q_row = qb * 64 + w * 16 + (lane & 15);           // A operand row of this lane
+  // Q fragments: lane holds Q[q_row][k = 32*ks + 8*(lane>>4) + j]
+  frag qf[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    frag z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (elem)0.f;
+    if (q_row < S) z = *(const frag*)(base + (size_t)q_row * ld + hh * DH + ks * 32 + (lane >> 4) * 8);
+    qf[ks] = z;
+  }
+  f32x4 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[4], l_run[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+
+  for (int k0 = 0; k0 < S; k0 += KB) {
+    __syncthreads();
+    // stage K (row-major) and V (transposed) of this key block; 256 threads x 16 B = one 64 x 32 slab per pass
+    for (int e = tid; e < KB * (DH / 8); e += 256) {
+      const int key = e / (DH / 8), c = e % (DH / 8);
+      frag kv, vv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kv[j] = (elem)0.f; vv[j] = (elem)0.f; }
+      if (k0 + key < S) {
+        kv = *(const frag*)(base + (size_t)(k0 + key) * ld + H + hh * DH + c * 8);
+        vv = *(const frag*)(base + (size_t)(k0 + key) * ld + 2 * H + hh * DH + c * 8);
+      }
+      *(frag*)&sK[key][c * 8] = kv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sVt[c * 8 + j][key] = vv[j];
+    }
+    if (tid < KB) sBias[tid] = (k0 + tid < S && mask[(size_t)bb * S + k0 + tid] != 0) ? 0.f : -1e30f;
+    __syncthreads();
+    // S = Q K^T  (16 q rows x 64 keys per wave): B operand lane holds K[key = 16*nf + (lane&15)][k chunk]
+    f32x4 sc[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      sc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const frag kf = *(const frag*)&sK[nf * 16 + (lane & 15)][ks * 32 + (lane >> 4) * 8];
+        sc[nf] = EMfma<DT>::run(qf[ks], kf, sc[nf]);
+      }
+    }
+    // online softmax: this lane's rows are (lane>>4)*4 + r, its columns 16*nf + (lane&15)
+    float p[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const float v = sc[nf][r] * scale + sBias[nf * 16 + (lane & 15)];
+        p[nf][r] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      const float m_new = fmaxf(m_run[r], mx);
+      const float alpha = __expf(m_run[r] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const float e = __expf(p[nf][r] - m_new);
+        p[nf][r] = e;
+        rs += e;
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off);
+      l_run[r] = l_run[r] * alpha + rs;
+      m_run[r] = m_new;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) o[d][r] *= alpha;
+    }
+    // P -> LDS (this wave's 16 x 64 slab), then O += P V
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[w][(lane >> 4) * 4 + r][nf * 16 + (lane & 15)] = (elem)p[nf][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < KB / 32; ++ks) {
+      const frag pf = *(const frag*)&sP[w][lane & 15][ks * 32 + (lane >> 4) * 8];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        const frag vf = *(const frag*)&sVt[d * 16 + (lane & 15)][ks * 32 + (lane >> 4) * 8];
+        o[d] = EMfma<DT>::run(pf, vf, o[d]);
+      }
+    }
+  }
+  // out[row][hh*DH + 16*d + (lane&15)], row = qb*64 + w*16 + (lane>>4)*4 + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = qb * 64 + w * 16 + (lane >> 4) * 4 + r;
+    if (row >= S) continue;
+    const float inv = 1.0f / l_run[r];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const elem v = (elem)(o[d][r] * inv);
+      __builtin_memcpy(&out[((size_t)bb * S + row) * H + hh * DH + d * 16 + (lane & 15)], &v, 2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pooling + L2 norm
+template <typename E>
+__global__ __launch_bounds__(256) void enc_pool_kernel(const E* __restrict__ x, const int32_t* __restrict__ mask, int B, int S, int H,
+                                                       int pool, int normalize, float* __restrict__ out) {
+  extern __shared__ float acc[];   // [H]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float red[256];
+  float cnt = 0.f;
+  if (pool == MRAG_POOL_MEAN) {
+    for (int s = 0; s < S; ++s) cnt += mask[(size_t)b * S + s] != 0 ? 1.f : 0.f;
+    cnt = fmaxf(cnt, 1e-9f);        // sentence-transformers clamps the token count
+  }
+  float ss = 0.f;
+  for (int i = tid; i < H; i += 256) {
+    float v;
+    if (pool == MRAG_POOL_CLS) v = (float)x[((size_t)b * S) * H + i];
+    else {
+      float a = 0.f;
+      for (int s = 0; s < S; ++s)
+        if (mask[(size_t)b * S + s] != 0) a += (float)x[((size_t)b * S + s) * H + i];
+      v = a / cnt;
+    }
+    acc[i] = v;
+    ss += v * v;
+  }
+  red[tid] = ss;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  const float nrm = normalize ? fmaxf(sqrtf(red[0]), 1e-12f) : 1.f;   // F.normalize eps
+  for (int i = tid; i < H; i += 256) out[(size_t)b * H + i] = acc[i] / nrm;
+}
+
+// ------------------------------------------------------------------ host side
+struct Linear {
+  uint16_t* w = nullptr;   // [N_pad][K]
+  float* b = nullptr;      // [N_pad]
+  int N = 0, K = 0, N_pad = 0;
+};
+
+struct Layer {
+  Linear qkv, attn_out, ffn_in, ffn_out;
+  float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+struct Encoder : Object {
+  mrag_encoder_config cfg;
+  float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_g = nullptr, *eln_b = nullptr;
+  std::vector<Layer> layers;
+  std::map<std::string, bool> have;
+  std::vector<void*> allocs;
+  DevBuf ids, mask, x, y, qkv, ctx, ffn, out, stage;
+  ~Encoder() override {
+    for (void* p : allocs) (void)hipFree(p);
+    for (DevBuf* b : {&ids, &mask, &x, &y, &qkv, &ctx, &ffn, &out, &stage}) b->release();
+  }
+};
+
+static int dev_alloc(Encoder* e, void** p, size_t bytes) {
+  hipError_t err = hipMalloc(p, bytes);
+  if (err != hipSuccess) return fail(MRAG_ERR_OOM, "hipMalloc(%zu) failed", bytes);
+  (void)hipMemset(*p, 0, bytes);
+  e->allocs.push_back(*p);
+  return MRAG_OK;
+}
+
+static int alloc_linear(Encoder* e, Linear& l, int N, int K) {
+  l.N = N; l.K = K; l.N_pad = (int)round_up(N, GN);
+  MRAG_TRY(dev_alloc(e, (void**)&l.w, (size_t)l.N_pad * K * 2));
+  MRAG_TRY(dev_alloc(e, (void**)&l.b, (size_t)l.N_pad * 4));
+  return MRAG_OK;
+}
+
+static std::vector<std::string> expected_params(const mrag_encoder_config& c) {
+  std::vector<std::string> v = {"embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+                                "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight",
+                                "embeddings.LayerNorm.bias"};
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string p = "encoder.layer." + std::to_string(i) + ".";
+    for (const char* s : {"attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
+                          "intermediate.dense", "output.dense"}) {
+      v.push_back(p + s + ".weight");
+      v.push_back(p + s + ".bias");
+    }
+    for (const char* s : {"attention.output.LayerNorm", "output.LayerNorm"}) {
+      v.push_back(p + s + ".weight");
+      v.push_back(p + s + ".bias");
+    }
+  }
+  return v;
+}
+
+// fp32 [rows][K] -> storage dtype at dst rows [row0, row0+rows) of a [N_pad][K] matrix
+static int upload_matrix(Encoder* e, const float* src, int is_device, int rows, int K, uint16_t* dst, int row0, hipStream_t stream) {
+  const void* s = src;
+  if (!is_device) {
+    MRAG_TRY(e->stage.ensure((size_t)rows * K * 4));
+    MRAG_HIP(hipMemcpyAsync(e->stage.p, src, (size_t)rows * K * 4, hipMemcpyHostToDevice, stream));
+    s = e->stage.p;
+  }
+  MRAG_TRY(launch_prep_rows(s, MRAG_F32, rows, K, dst + (size_t)row0 * K, K, e->cfg.compute_dtype, 0, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  return MRAG_OK;
+}
+
+static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hipStream_t stream) {
+  MRAG_HIP(hipMemcpyAsync(dst, src, (size_t)n * 4, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  return MRAG_OK;
+}
+
+template <int DT>
+static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M_pad, int epi, hipStream_t stream) {
+  const int tiles_m = M_pad / GM, tiles_n = l.N_pad / GN;
+  const dim3 grid((unsigned)(tiles_m * tiles_n)), block(GTHR);
+  if (epi == EPI_BIAS) hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_BIAS>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
+  else if (epi == EPI_GELU) hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_GELU>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
+  else hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_RESID>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
+template <int DT>
+static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int normalize, hipStream_t stream) {
+  typedef typename EMfma<DT>::elem elem;
+  const mrag_encoder_config& c = e->cfg;
+  const int H = c.hidden, I = c.intermediate;
+  const int64_t M = (int64_t)B * S;
+  const int M_pad = (int)round_up(M, GM);
+  MRAG_TRY(e->x.ensure((size_t)M_pad * H * 2));
+  MRAG_TRY(e->y.ensure((size_t)M_pad * H * 2));
+  MRAG_TRY(e->qkv.ensure((size_t)M_pad * 3 * H * 2));
+  MRAG_TRY(e->ctx.ensure((size_t)M_pad * H * 2));
+  MRAG_TRY(e->ffn.ensure((size_t)M_pad * I * 2));
+  uint16_t *x = (uint16_t*)e->x.p, *y = (uint16_t*)e->y.p, *qkv = (uint16_t*)e->qkv.p, *ctx = (uint16_t*)e->ctx.p, *ffn = (uint16_t*)e->ffn.p;
+  if (M_pad > M) {   // padding rows feed the GEMMs: keep them finite
+    MRAG_HIP(hipMemsetAsync(x + (size_t)M * H, 0, (size_t)(M_pad - M) * H * 2, stream));
+    MRAG_HIP(hipMemsetAsync(ctx + (size_t)M * H, 0, (size_t)(M_pad - M) * H * 2, stream));
+  }
+  const dim3 tok_grid((unsigned)((M + 3) / 4)), tok_block(256);
+  hipLaunchKernelGGL((enc_embed_ln_kernel<elem>), tok_grid, tok_block, 0, stream, (const int32_t*)e->ids.p, M, S, H, c.vocab_size,
+                     e->word, e->pos, e->type, e->eln_g, e->eln_b, c.layer_norm_eps, (elem*)x);
+  MRAG_HIP(hipGetLastError());
+  const int dh = H / c.heads;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const dim3 agrid((unsigned)(B * c.heads * ((S + 63) / 64)));
+  for (int li = 0; li < c.layers; ++li) {
+    Layer& L = e->layers[li];
+    MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, M_pad, EPI_BIAS, stream));
+    if (dh == 32) hipLaunchKernelGGL((enc_attention_kernel<DT, 32>), agrid, dim3(256), 0, stream, qkv, (const int32_t*)e->mask.p, ctx, B, S, H, c.heads, scale);
+    else if (dh == 64) hipLaunchKernelGGL((enc_attention_kernel<DT, 64>), agrid, dim3(256), 0, stream, qkv, (const int32_t*)e->mask.p, ctx, B, S, H, c.heads, scale);
+    else return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
+    MRAG_HIP(hipGetLastError());
+    MRAG_TRY(run_gemm<DT>(ctx, L.attn_out, x, y, M_pad, EPI_RESID, stream));                    // y = ctx Wo + b + x
+    hipLaunchKernelGGL((enc_ln_kernel<elem>), tok_grid, tok_block, 0, stream, (const elem*)y, M, H, L.ln1_g, L.ln1_b, c.layer_norm_eps, (elem*)x);
+    MRAG_TRY(run_gemm<DT>(x, L.ffn_in, nullptr, ffn, M_pad, EPI_GELU, stream));                  // ffn = gelu(x W1 + b1)
+    MRAG_TRY(run_gemm<DT>(ffn, L.ffn_out, x, y, M_pad, EPI_RESID, stream));                      // y = ffn W2 + b2 + x
+    hipLaunchKernelGGL((enc_ln_kernel<elem>), tok_grid, tok_block, 0, stream, (const elem*)y, M, H, L.ln2_g, L.ln2_b, c.layer_norm_eps, (elem*)x);
+    MRAG_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL((enc_pool_kernel<elem>), dim3((unsigned)B), dim3(256), (size_t)H * 4, stream, (const elem*)x, (const int32_t*)e->mask.p, B, S, H,
+                     pool, normalize, d_out);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
+}  // namespace mrag
+
+using namespace mrag;
+
+extern "C" {
+
+int mrag_encoder_create(const mrag_encoder_config* cfg, int device, mrag_handle* out) {
+  if (!cfg || !out) return fail(MRAG_ERR_INVALID, "NULL argument");
+  const mrag_encoder_config& c = *cfg;
+  if (c.hidden <= 0 || c.hidden % 64 || c.heads <= 0 || c.hidden % c.heads || c.layers <= 0 || c.intermediate <= 0 ||
+      c.intermediate % 64 || c.vocab_size <= 0 || c.max_position <= 0 || c.type_vocab_size <= 0)
+    return fail(MRAG_ERR_INVALID, "bad encoder config (hidden and intermediate must be multiples of 64)");
+  const int dh = c.hidden / c.heads;
+  if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
+  if (c.compute_dtype != MRAG_F16 && c.compute_dtype != MRAG_BF16) return fail(MRAG_ERR_INVALID, "compute dtype must be fp16 or bf16");
+  MRAG_TRY(use_device(device));
+  Encoder* e = new Encoder();
+  e->kind = KIND_ENCODER; e->device = device; e->cfg = c;
+  int st = MRAG_OK;
+  const int H = c.hidden;
+  if (st == MRAG_OK) st = dev_alloc(e, (void**)&e->word, (size_t)c.vocab_size * H * 4);
+  if (st == MRAG_OK) st = dev_alloc(e, (void**)&e->pos, (size_t)c.max_position * H * 4);
+  if (st == MRAG_OK) st = dev_alloc(e, (void**)&e->type, (size_t)c.type_vocab_size * H * 4);
+  if (st == MRAG_OK) st = dev_alloc(e, (void**)&e->eln_g, (size_t)H * 4);
+  if (st == MRAG_OK) st = dev_alloc(e, (void**)&e->eln_b, (size_t)H * 4);
+  e->layers.resize(c.layers);
+  for (int i = 0; i < c.layers && st == MRAG_OK; ++i) {
+    Layer& L = e->layers[i];
+    if (st == MRAG_OK) st = alloc_linear(e, L.qkv, 3 * H, H);
+    if (st == MRAG_OK) st = alloc_linear(e, L.attn_out, H, H);
+    if (st == MRAG_OK) st = alloc_linear(e, L.ffn_in, c.intermediate, H);
+    if (st == MRAG_OK) st = alloc_linear(e, L.ffn_out, H, c.intermediate);
+    for (float** p : {&L.ln1_g, &L.ln1_b, &L.ln2_g, &L.ln2_b})
+      if (st == MRAG_OK) st = dev_alloc(e, (void**)p, (size_t)H * 4);
+  }
+  if (st != MRAG_OK) { delete e; return st; }
+  *out = register_object(e);
+  return MRAG_OK;
+}
+
+int mrag_encoder_destroy(mrag_handle h) {
+  Object* o = take(h, KIND_ENCODER);
+  if (!o) return MRAG_ERR_INVALID;
+  (void)hipSetDevice(o->device);
+  (void)hipDeviceSynchronize();
+  delete o;
+  return MRAG_OK;
+}
+
+int mrag_encoder_set_param(mrag_handle h, const char* name, const float* data, int64_t numel, int is_device, void* stream_) {
+  Encoder* e = (Encoder*)lookup(h, KIND_ENCODER);
+  if (!e) return MRAG_ERR_INVALID;
+  if (!name || !data) return fail(MRAG_ERR_INVALID, "NULL argument");
+  MRAG_TRY(use_device(e->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const mrag_encoder_config& c = e->cfg;
+  const int H = c.hidden, I = c.intermediate;
+  const std::string n(name);
+  auto need = [&](int64_t want) -> int {
+    return numel == want ? MRAG_OK : fail(MRAG_ERR_INVALID, "%s: expected %lld elements, got %lld", name, (long long)want, (long long)numel);
+  };
+  int st = MRAG_OK;
+  if (n == "embeddings.word_embeddings.weight") { MRAG_TRY(need((int64_t)c.vocab_size * H)); st = upload_f32(data, is_device, numel, e->word, stream); }
+  else if (n == "embeddings.position_embeddings.weight") { MRAG_TRY(need((int64_t)c.max_position * H)); st = upload_f32(data, is_device, numel, e->pos, stream); }
+  else if (n == "embeddings.token_type_embeddings.weight") { MRAG_TRY(need((int64_t)c.type_vocab_size * H)); st = upload_f32(data, is_device, numel, e->type, stream); }
+  else if (n == "embeddings.LayerNorm.weight") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, numel, e->eln_g, stream); }
+  else if (n == "embeddings.LayerNorm.bias") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, numel, e->eln_b, stream); }
+  else if (n.rfind("encoder.layer.", 0) == 0) {
+    const size_t dot = n.find('.', 14);
+    if (dot == std::string::npos) return fail(MRAG_ERR_INVALID, "unknown parameter %s", name);
+    const int li = atoi(n.substr(14, dot - 14).c_str());
+    if (li < 0 || li >= c.layers) return fail(MRAG_ERR_INVALID, "%s: layer out of range", name);
+    Layer& L = e->layers[li];
+    const std::string r = n.substr(dot + 1);
+    auto qkv_part = [&](int part, bool is_w) -> int {
+      if (is_w) { MRAG_TRY(need((int64_t)H * H)); return upload_matrix(e, data, is_device, H, H, L.qkv.w, part * H, stream); }
+      MRAG_TRY(need(H));
+      return upload_f32(data, is_device, H, L.qkv.b + part * H, stream);
+    };
+    if (r == "attention.self.query.weight") st = qkv_part(0, true);
+    else if (r == "attention.self.query.bias") st = qkv_part(0, false);
+    else if (r == "attention.self.key.weight") st = qkv_part(1, true);
+    else if (r == "attention.self.key.bias") st = qkv_part(1, false);
+    else if (r == "attention.self.value.weight") st = qkv_part(2, true);
+    else if (r == "attention.self.value.bias") st = qkv_part(2, false);
+    else if (r == "attention.output.dense.weight") { MRAG_TRY(need((int64_t)H * H)); st = upload_matrix(e, data, is_device, H, H, L.attn_out.w, 0, stream); }
+    else if (r == "attention.output.dense.bias") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.attn_out.b, stream); }
+    else if (r == "attention.output.LayerNorm.weight") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.ln1_g, stream); }
+    else if (r == "attention.output.LayerNorm.bias") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.ln1_b, stream); }
+    else if (r == "intermediate.dense.weight") { MRAG_TRY(need((int64_t)I * H)); st = upload_matrix(e, data, is_device, I, H, L.ffn_in.w, 0, stream); }
+    else if (r == "intermediate.dense.bias") { MRAG_TRY(need(I)); st = upload_f32(data, is_device, I, L.ffn_in.b, stream); }
+    else if (r == "output.dense.weight") { MRAG_TRY(need((int64_t)H * I)); st = upload_matrix(e, data, is_device, H, I, L.ffn_out.w, 0, stream); }
+    else if (r == "output.dense.bias") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.ffn_out.b, stream); }
+    else if (r == "output.LayerNorm.weight") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.ln2_g, stream); }
+    else if (r == "output.LayerNorm.bias") { MRAG_TRY(need(H)); st = upload_f32(data, is_device, H, L.ln2_b, stream); }
+    else return fail(MRAG_ERR_INVALID, "unknown parameter %s", name);
+  } else {
+    return fail(MRAG_ERR_INVALID, "unknown parameter %s", name);
+  }
+  if (st == MRAG_OK) e->have[n] = true;
+  return st;
+}
+
+int mrag_encoder_missing_params(mrag_handle h, int* out_missing) {
+  Encoder* e = (Encoder*)lookup(h, KIND_ENCODER);
+  if (!e) return MRAG_ERR_INVALID;
+  if (!out_missing) return fail(MRAG_ERR_INVALID, "out_missing is NULL");
+  int miss = 0;
+  std::string first;
+  for (const std::string& n : expected_params(e->cfg))
+    if (!e->have.count(n)) { if (!miss) first = n; ++miss; }
+  if (miss) set_error("%d parameters missing, first: %s", miss, first.c_str());
+  *out_missing = miss;
+  return MRAG_OK;
+}
+
+int mrag_encoder_forward(mrag_handle h, const int32_t* ids, const int32_t* mask, int B, int S, float* out, int pool, int normalize,
+                         int io_is_device, void* stream_) {
+  Encoder* e = (Encoder*)lookup(h, KIND_ENCODER);
+  if (!e) return MRAG_ERR_INVALID;
+  if (B < 0 || S <= 0) return fail(MRAG_ERR_INVALID, "bad batch shape B=%d S=%d", B, S);
+  if (S > e->cfg.max_position) return fail(MRAG_ERR_INVALID, "sequence length %d exceeds max_position %d", S, e->cfg.max_position);
+  if (pool != MRAG_POOL_MEAN && pool != MRAG_POOL_CLS) return fail(MRAG_ERR_INVALID, "unknown pooling %d", pool);
+  if (B == 0) return MRAG_OK;
+  if (!ids || !mask || !out) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  if ((int64_t)B * S > (1ll << 30)) return fail(MRAG_ERR_UNSUPPORTED, "batch too large; split it");
+  int miss = 0;
+  MRAG_TRY(mrag_encoder_missing_params(h, &miss));
+  if (miss) return fail(MRAG_ERR_INVALID, "encoder has %d unset parameters (%s)", miss, mrag_last_error());
+  MRAG_TRY(use_device(e->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nb = (size_t)B * S * 4;
+  MRAG_TRY(e->ids.ensure(nb));
+  MRAG_TRY(e->mask.ensure(nb));
+  const hipMemcpyKind kin = io_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  MRAG_HIP(hipMemcpyAsync(e->ids.p, ids, nb, kin, stream));
+  MRAG_HIP(hipMemcpyAsync(e->mask.p, mask, nb, kin, stream));
+  float* d_out = out;
+  if (!io_is_device) { MRAG_TRY(e->out.ensure((size_t)B * e->cfg.hidden * 4)); d_out = (float*)e->out.p; }
+  if (e->cfg.compute_dtype == MRAG_F16) MRAG_TRY(forward_impl<MRAG_F16>(e, B, S, d_out, pool, normalize, stream));
+  else MRAG_TRY(forward_impl<MRAG_BF16>(e, B, S, d_out, pool, normalize, stream));
+  if (!io_is_device) {
+    MRAG_HIP(hipMemcpyAsync(out, d_out, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, stream));
+    MRAG_HIP(hipStreamSynchronize(stream));
+  }
+  return MRAG_OK;
+}
+
+}  // extern "C"

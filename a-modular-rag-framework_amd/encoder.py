@@ -1,0 +1,223 @@
+"""HIP sentence encoder behind the provider boundary (a5: the ``LLMProvider.embed`` slot,
+app/core/providers/base.py:6).  BERT-family forward in HIP (csrc/encoder.hip) through the C ABI;
+tokenisation stays on the host.
+
+Weights: a local HF directory (``config.json`` + ``model.safetensors`` / ``pytorch_model.bin``
+loaded with ``weights_only=True`` + ``vocab.txt``) when one exists on the box; otherwise seeded
+synthetic parameters of the named architecture and a hashing tokenizer -- the container has no
+checkpoints and no network.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import re
+import zlib
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _native as N
+
+# public model-card shapes (not in the reference); overridden by config.json when weights are local
+ARCHS = {
+    "minilm-l6": dict(vocab_size=30522, hidden=384, layers=6, heads=12, intermediate=1536, max_position=512,
+                      type_vocab_size=2, layer_norm_eps=1e-12, pool="mean", max_length=256),
+    "bge-base": dict(vocab_size=30522, hidden=768, layers=12, heads=12, intermediate=3072, max_position=512,
+                     type_vocab_size=2, layer_norm_eps=1e-12, pool="cls", max_length=512),
+    "tiny": dict(vocab_size=1000, hidden=64, layers=2, heads=2, intermediate=256, max_position=128,
+                 type_vocab_size=2, layer_norm_eps=1e-12, pool="mean", max_length=64),
+    "small": dict(vocab_size=2000, hidden=128, layers=2, heads=2, intermediate=512, max_position=256,
+                  type_vocab_size=2, layer_norm_eps=1e-12, pool="cls", max_length=128),
+}
+
+
+class EncoderSpec:
+    def __init__(self, **kw):
+        self.vocab_size = int(kw["vocab_size"]); self.hidden = int(kw["hidden"]); self.layers = int(kw["layers"])
+        self.heads = int(kw["heads"]); self.intermediate = int(kw["intermediate"])
+        self.max_position = int(kw["max_position"]); self.type_vocab_size = int(kw.get("type_vocab_size", 2))
+        self.layer_norm_eps = float(kw.get("layer_norm_eps", 1e-12))
+        self.pool = kw.get("pool", "mean"); self.max_length = int(kw.get("max_length") or self.max_position)
+
+    def as_dict(self):
+        return dict(vocab_size=self.vocab_size, hidden=self.hidden, layers=self.layers, heads=self.heads,
+                    intermediate=self.intermediate, max_position=self.max_position,
+                    type_vocab_size=self.type_vocab_size, layer_norm_eps=self.layer_norm_eps, pool=self.pool)
+
+
+def seeded_weights(spec: EncoderSpec, seed: int) -> Dict[str, np.ndarray]:
+    """Deterministic fp32 parameters (N(0,0.05) matrices, 0.02 N(0,1) biases, LayerNorm gains
+    1 + 0.1 N(0,1)), drawn in HF state-dict order from ``default_rng(seed)``."""
+    H, I = spec.hidden, spec.intermediate
+    names = [("embeddings.word_embeddings.weight", (spec.vocab_size, H)),
+             ("embeddings.position_embeddings.weight", (spec.max_position, H)),
+             ("embeddings.token_type_embeddings.weight", (spec.type_vocab_size, H)),
+             ("embeddings.LayerNorm.weight", (H,)), ("embeddings.LayerNorm.bias", (H,))]
+    for i in range(spec.layers):
+        p = f"encoder.layer.{i}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            names += [(p + n + ".weight", (H, H)), (p + n + ".bias", (H,))]
+        names += [(p + "intermediate.dense.weight", (I, H)), (p + "intermediate.dense.bias", (I,)),
+                  (p + "output.dense.weight", (H, I)), (p + "output.dense.bias", (H,))]
+        for n in ("attention.output.LayerNorm", "output.LayerNorm"):
+            names += [(p + n + ".weight", (H,)), (p + n + ".bias", (H,))]
+    # same draw order as a dict built embeddings -> per layer {q,k,v,o (w,b)}, ffn, LNs
+    order = {}
+    for name, shape in names:
+        order[name] = shape
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    # NOTE: iteration order must match oracle.encoder.param_shapes (tests compare both generators)
+    H_first = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+               "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+    seq = list(H_first)
+    for i in range(spec.layers):
+        p = f"encoder.layer.{i}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            seq += [p + n + ".weight", p + n + ".bias"]
+        seq += [p + "intermediate.dense.weight", p + "intermediate.dense.bias", p + "output.dense.weight", p + "output.dense.bias"]
+        for n in ("attention.output.LayerNorm", "output.LayerNorm"):
+            seq += [p + n + ".weight", p + n + ".bias"]
+    for name in seq:
+        shape = order[name]
+        if name.endswith("LayerNorm.weight"):
+            out[name] = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        elif name.endswith(".bias"):
+            out[name] = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            out[name] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+    return out
+
+
+class HashingTokenizer:
+    """Stand-in for WordPiece when no vocab.txt is on disk: lower-case, split on non-alphanumerics
+    (the reference's own tokeniser for BM25, text_index.py:10-11), token -> crc32 bucket.
+    [PAD]=0, [CLS]=101, [SEP]=102 like BERT."""
+
+    PAD, CLS, SEP = 0, 101, 102
+
+    def __init__(self, vocab_size: int):
+        self.vocab_size = vocab_size
+        self.lo = min(1000, max(3, vocab_size // 10))
+
+    def encode(self, text: str, max_length: int) -> List[int]:
+        toks = [t for t in re.split(r"[^a-zA-Z0-9]+", (text or "").lower()) if t]
+        ids = [self.lo + zlib.crc32(t.encode()) % (self.vocab_size - self.lo) for t in toks][: max_length - 2]
+        cls, sep = min(self.CLS, self.vocab_size - 1), min(self.SEP, self.vocab_size - 1)
+        return [cls] + ids + [sep]
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab_file: str):
+        from tokenizers import BertWordPieceTokenizer
+        self._tok = BertWordPieceTokenizer(vocab_file, lowercase=True)
+
+    def encode(self, text: str, max_length: int) -> List[int]:
+        return self._truncate(self._tok.encode(text or "").ids, max_length)
+
+    @staticmethod
+    def _truncate(ids: List[int], max_length: int) -> List[int]:
+        return ids if len(ids) <= max_length else ids[: max_length - 1] + [ids[-1]]
+
+
+class HipSentenceEncoder:
+    def __init__(self, spec: EncoderSpec, weights: Dict[str, np.ndarray], tokenizer=None, device: int = 0,
+                 dtype: str = "f16", max_length: Optional[int] = None):
+        self._lib = N.load()
+        self.spec, self.device = spec, int(device)
+        self.max_length = int(max_length or spec.max_length)
+        self.tokenizer = tokenizer or HashingTokenizer(spec.vocab_size)
+        cfg = N.EncoderConfig(spec.vocab_size, spec.hidden, spec.layers, spec.heads, spec.intermediate, spec.max_position,
+                              spec.type_vocab_size, spec.layer_norm_eps, N.MRAG_F16 if dtype == "f16" else N.MRAG_BF16)
+        h = C.c_uint64(0)
+        N.check(self._lib.mrag_encoder_create(C.byref(cfg), self.device, C.byref(h)))
+        self._h = h
+        for name, arr in weights.items():
+            name = name[5:] if name.startswith("bert.") else name
+            if name.startswith("pooler.") or name.endswith("position_ids"):
+                continue
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            N.check(self._lib.mrag_encoder_set_param(self._h, name.encode(), a.ctypes.data, a.size, 0, None))
+        miss = C.c_int(0)
+        N.check(self._lib.mrag_encoder_missing_params(self._h, C.byref(miss)))
+        if miss.value:
+            raise ValueError(f"encoder weights incomplete: {self._lib.mrag_last_error().decode()}")
+
+    # -- construction -----------------------------------------------------------------------------
+    @classmethod
+    def from_seed(cls, arch: str = "minilm-l6", seed: int = 0, **kw) -> "HipSentenceEncoder":
+        spec = EncoderSpec(**ARCHS[arch])
+        return cls(spec, seeded_weights(spec, seed), **kw)
+
+    @classmethod
+    def from_pretrained_dir(cls, path: str, **kw) -> "HipSentenceEncoder":
+        p = Path(path)
+        cfg = json.loads((p / "config.json").read_text())
+        pool = "mean"
+        st_cfg = p / "1_Pooling" / "config.json"
+        if st_cfg.exists():
+            pc = json.loads(st_cfg.read_text())
+            pool = "cls" if pc.get("pooling_mode_cls_token") else "mean"
+        spec = EncoderSpec(vocab_size=cfg["vocab_size"], hidden=cfg["hidden_size"], layers=cfg["num_hidden_layers"],
+                           heads=cfg["num_attention_heads"], intermediate=cfg["intermediate_size"],
+                           max_position=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
+                           layer_norm_eps=cfg.get("layer_norm_eps", 1e-12), pool=pool,
+                           max_length=kw.get("max_length") or min(512, cfg["max_position_embeddings"]))
+        if (p / "model.safetensors").exists():
+            from safetensors.numpy import load_file
+            weights = load_file(str(p / "model.safetensors"))
+        else:
+            import torch
+            sd = torch.load(str(p / "pytorch_model.bin"), map_location="cpu", weights_only=True)
+            weights = {k: v.float().numpy() for k, v in sd.items()}
+        tok = WordPieceTokenizer(str(p / "vocab.txt")) if (p / "vocab.txt").exists() else None
+        return cls(spec, weights, tokenizer=tok, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mrag_encoder_destroy(self._h)
+            self._h = C.c_uint64(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward ----------------------------------------------------------------------------------
+    def forward(self, ids: np.ndarray, mask: np.ndarray, pool: Optional[str] = None, normalize: bool = True) -> np.ndarray:
+        """ids/mask int32 [B,S] -> float32 [B,hidden]."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        B, S = ids.shape
+        out = np.empty((B, self.spec.hidden), dtype=np.float32)
+        pool = pool or self.spec.pool
+        N.check(self._lib.mrag_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, B, S, out.ctypes.data,
+                                               N.POOL_CLS if pool == "cls" else N.POOL_MEAN, int(bool(normalize)), 0, None))
+        return out
+
+    def tokenize(self, texts: List[str]):
+        seqs = [self.tokenizer.encode(t, self.max_length) for t in texts]
+        S = max(16, -(-max(len(s) for s in seqs) // 16) * 16)
+        S = min(S, self.spec.max_position)
+        ids = np.zeros((len(seqs), S), dtype=np.int32)
+        mask = np.zeros((len(seqs), S), dtype=np.int32)
+        for i, s in enumerate(seqs):
+            s = s[:S]
+            ids[i, :len(s)] = s
+            mask[i, :len(s)] = 1
+        return ids, mask
+
+    def encode(self, texts: List[str], batch_size: int = 256, normalize: bool = True) -> np.ndarray:
+        """Texts -> [n, hidden] float32.  Batches are formed in length order (less padding) and the
+        rows are returned in input order."""
+        n = len(texts)
+        out = np.empty((n, self.spec.hidden), dtype=np.float32)
+        order = sorted(range(n), key=lambda i: len(texts[i]))
+        for lo in range(0, n, batch_size):
+            sel = order[lo:lo + batch_size]
+            ids, mask = self.tokenize([texts[i] for i in sel])
+            out[sel] = self.forward(ids, mask, normalize=normalize)
+        return out

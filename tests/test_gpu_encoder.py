@@ -1,0 +1,151 @@
+"""GPU parity of the HIP sentence encoder (K6) against the CPU oracle (itself pinned to HF BertModel in
+tests/test_encoder_oracle.py), within the north-star 1e-3; plus the provider / backend end to end."""
+import json
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import encoder as oe
+from oracle import dense_search as ds
+from oracle import ref_semantics as rs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _batch(spec, B, S, seed, lens=None):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(3, spec["vocab_size"], size=(B, S)).astype(np.int32)
+    mask = np.ones((B, S), dtype=np.int32)
+    lens = lens or [int(x) for x in rng.integers(1, S + 1, size=B)]
+    for b, L in enumerate(lens):
+        mask[b, L:] = 0
+        ids[b, L:] = 0
+    return ids, mask
+
+
+@pytest.mark.parametrize("arch,B,S,pool", [("tiny", 7, 16, "mean"), ("tiny", 3, 100, "cls"), ("small", 9, 80, "cls"),
+                                            ("small", 4, 256, "mean")])
+def test_small_archs_match_oracle(arch, B, S, pool):
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, ARCHS, seeded_weights
+    spec = oe.SPECS[arch]
+    w = oe.seeded_weights(spec, 21)
+    enc = HipSentenceEncoder(EncoderSpec(**ARCHS[arch]), w)
+    ids, mask = _batch(spec, B, S, 3)
+    got = enc.forward(ids, mask, pool=pool)
+    want = oe.forward(spec, w, ids, mask, pool=pool)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+    raw = enc.forward(ids, mask, pool=pool, normalize=False)
+    np.testing.assert_allclose(raw, oe.forward(spec, w, ids, mask, pool=pool, normalize=False), rtol=0, atol=5e-3)
+
+
+def test_minilm_l6_shape_matches_oracle():
+    """BASELINE config 1 encoder shape (6 layers, 384 hidden, 12 heads, 1536 FFN), seeded weights."""
+    from mrag_amd.encoder import HipSentenceEncoder
+    spec = dict(oe.SPECS["minilm-l6"], vocab_size=4000)          # full 30522-row table not needed for arithmetic parity
+    from mrag_amd.encoder import EncoderSpec
+    w = oe.seeded_weights(spec, 7)
+    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w)
+    ids, mask = _batch(spec, 16, 64, 9)
+    got = enc.forward(ids, mask, pool="mean")
+    want = oe.forward(spec, w, ids, mask, pool="mean")
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+    assert np.abs(got - want).max() < 5e-4
+
+
+def test_bge_base_shape_matches_oracle_cls():
+    """BASELINE config 3 encoder shape (12 layers, 768 hidden, 12 heads, 3072 FFN), CLS pooling."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec
+    spec = dict(oe.SPECS["bge-base"], vocab_size=3000, max_position=128)
+    w = oe.seeded_weights(spec, 8)
+    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w)
+    ids, mask = _batch(spec, 6, 48, 10)
+    got = enc.forward(ids, mask, pool="cls")
+    want = oe.forward(spec, w, ids, mask, pool="cls")
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+
+
+def test_bf16_compute_and_errors():
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, ARCHS
+    from mrag_amd._native import MragError
+    spec = oe.SPECS["tiny"]
+    w = oe.seeded_weights(spec, 2)
+    enc = HipSentenceEncoder(EncoderSpec(**ARCHS["tiny"]), w, dtype="bf16")
+    ids, mask = _batch(spec, 4, 32, 1)
+    np.testing.assert_allclose(enc.forward(ids, mask), oe.forward(spec, w, ids, mask), rtol=0, atol=8e-3)
+    with pytest.raises(MragError):
+        enc.forward(np.zeros((1, 129), np.int32), np.ones((1, 129), np.int32))     # beyond max_position
+    w2 = dict(w); w2.pop("encoder.layer.1.output.dense.bias")
+    with pytest.raises(ValueError):
+        HipSentenceEncoder(EncoderSpec(**ARCHS["tiny"]), w2)
+
+
+def test_provider_and_backend_end_to_end(tmp_path):
+    """B1 + B2 + B3 on a HotpotQA-shaped synthetic docs.jsonl: provider -> router -> DenseRetrievalBackend
+    -> DenseRetrievalAgent, checked against the oracle (oracle encoder + brute force + reference fusion)."""
+    from mrag_amd import corpus
+    from mrag_amd.adapter import DenseRetrievalAgent
+    from mrag_amd.backend import HipDenseReranker
+    from mrag_amd.dto import RetrievalIn
+    from mrag_amd.provider import HipEmbeddingProvider
+
+    rng = np.random.default_rng(4)
+    vocab = ["alpha", "beta", "gamma", "delta", "river", "city", "born", "film", "band", "album", "war", "king"]
+    rows = []
+    for t in range(60):
+        for sid in range(int(rng.integers(2, 6))):
+            rows.append({"doc_id": f"Title {t}#{sid}", "title": f"Title {t}", "sent_id": sid,
+                         "text": " ".join(rng.choice(vocab, size=int(rng.integers(5, 12))))})
+    docs = tmp_path / "docs.jsonl"
+    corpus.write_docs_jsonl(docs, rows)
+
+    prov = HipEmbeddingProvider(arch="tiny", seed=5, embed_model="tiny-seed5")
+    assert prov.kwargs["embed_model"] == "tiny-seed5"
+
+    class Router:                       # LLMRouter.embed restated (oracle.ref_semantics.router_embed)
+        providers, policy = {"hip": prov}, {"embedding_provider": "hip"}
+        def embed(self, *, model_hint, texts, require=None):
+            return rs.router_embed(self.providers, self.policy, model_hint=model_hint, texts=texts, require=require)
+    router = Router()
+
+    # provider vectors == oracle encoder on the same token ids
+    texts = [r["text"] for r in rows[:9]]
+    ids, mask = prov.encoder.tokenize(texts)
+    spec = oe.SPECS["tiny"]
+    want = oe.forward(spec, oe.seeded_weights(spec, 5), ids, mask, pool="mean")
+    got = np.asarray(prov.embed(model="x", texts=texts, require={})["vectors"])
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+
+    settings = {"modules": {"retrieval": {"impl": "mrag_amd.backend:DenseRetrievalBackend",
+                                          "impl_kwargs": {"index_path": str(docs), "alpha_dense": 0.4,
+                                                          "cache_dir": str(tmp_path / "cache"), "dense_pool_k": 20}}}}
+    agent = DenseRetrievalAgent.from_settings(settings, router=router)
+    query = "gamma river born king"
+    out = agent.retrieve(RetrievalIn(query=query, graph_id="", top_k=5, trace_id="t"))
+    assert len(out.hits) == 5 and out.diagnostics["dense_error"] is None and out.diagnostics["dense_scored"] >= 5
+    # oracle: encode everything with the oracle encoder, brute force, fuse with the reference rule
+    all_ids, all_mask = prov.encoder.tokenize([r["text"] for r in rows])
+    E = oe.forward(spec, oe.seeded_weights(spec, 5), all_ids, all_mask, pool="mean")
+    qi, qm = prov.encoder.tokenize([query])
+    qe = oe.forward(spec, oe.seeded_weights(spec, 5), qi, qm, pool="mean")
+    rv, ri = ds.brute_force_topk(ds.normalize_round(qe), ds.normalize_round(E), 20)
+    top_rows = [rows[int(i)] for i in ri[0][:5]]
+    got_texts = [h.meta["text"] for h in out.hits]
+    assert len(set(got_texts) & {r["text"] for r in top_rows}) >= 4          # fp16 encoder noise may swap one near-tie
+    assert out.hits[0].meta["score_dense_norm"] == 1.0 and out.hits[0].score == pytest.approx(0.4)
+    assert all(h.id.startswith("sent::Title ") for h in out.hits)
+    # second agent instance reuses the process-wide index (no re-embedding) and the disk cache exists
+    assert any((tmp_path / "cache").glob("*.npy"))
+    agent2 = DenseRetrievalAgent.from_settings(settings, router=router)
+    assert agent2.backend._get_state("tiny-seed5", "t") is agent.backend._get_state("tiny-seed5", "t")
+
+    # a2 drop-in: GPU cosine re-ranker == reference formula on the provider's vectors
+    cands = [{"id": f"sent::{r['doc_id']}::{r['sent_id'] or ''}", "score": 1.0, "meta": {"text": r["text"]}} for r in rows[:30]]
+    rr = HipDenseReranker(router, max_pool=25, embed_batch=8)
+    scores = rr.score(query=query, candidates=cands, trace_id="t")
+    ref = rs.dense_score(router.embed, query=query, candidates=cands, trace_id="t", max_pool=25, embed_batch=8,
+                         model_hint="tiny-seed5")
+    assert list(scores) == list(ref)
+    np.testing.assert_allclose(list(scores.values()), list(ref.values()), rtol=0, atol=1e-12)
