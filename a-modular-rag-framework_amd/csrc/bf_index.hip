@@ -67,7 +67,6 @@ constexpr int NGRP = 8;                   // lanes (2 waves x 4 lane groups) tha
 constexpr int SEG = 64;                   // private list segment per (query, lane group)
 constexpr int KEPT = 64;                  // compacted entries per query (= largest k)
 constexpr int QCAP = KEPT + NGRP * SEG;   // 576 list entries per (workgroup, query)
-constexpr int NCNT = 1 + NGRP;            // counters per query: kept + 8 segments
 constexpr int KMAX = KEPT;
 constexpr int K_CERT = 16;                // k served by the 16-row threshold certificate
 
@@ -98,7 +97,7 @@ struct BfParams {
   long long* stamps;        // dbg & 16: block 0 / wave 0 writes s_memtime stamps here
   uint32_t* list_sc;        // [T*S][256][QCAP]  score bits   (SoA: two dword stores per push)
   uint32_t* list_row;       // [T*S][256][QCAP]  local row
-  int* counts;              // [T*S][256][NCNT]
+  int* counts;              // [T*S][256] entries left in the kept area
 };
 
 __device__ __forceinline__ uint32_t f32_ord(float f) {
@@ -178,26 +177,13 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 // through `scratch` (>= QCAP u64 of LDS: the stage buffer the K loop has just consumed), then
 // ranked by counting with broadcast LDS reads.  Register-light on purpose (it shares the
 // kernel's 256-VGPR budget with the 128 accumulators); slow, and rare by construction.
-__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k,
-                                              int lane, uint64_t* __restrict__ scratch) {
+
+// Rank the `total` keys staged in `scratch` and write the k best (sorted) into the kept area.
+__device__ __forceinline__ void rank_and_keep(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k, int lane,
+                                              const uint64_t* __restrict__ scratch, int total) {
   float* tau_c = (float*)(smem + OFF_TAU);
   int* kcnt = (int*)(smem + OFF_KCNT);
   int* scnt = (int*)(smem + OFF_SCNT);
-  const int kc = kcnt[q];
-  int total = 0;
-#pragma unroll 1
-  for (int r = 0; r < QCAP / 64; ++r) {
-    const int idx = r * 64 + lane;
-    bool valid;
-    if (idx < KEPT) valid = idx < kc;
-    else valid = ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
-    uint64_t key = 0ull;
-    if (valid) key = make_key(lsc[idx], lrow[idx]);   // never 0 for a valid entry (row < 2^31)
-    const unsigned long long bal = __ballot(valid);
-    if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-    total += __popcll(bal);
-  }
-  // (one wave: program order + the LDS queue order make the staged keys visible to every lane)
 #pragma unroll 1
   for (int base = 0; base < total; base += 64) {
     const int i = base + lane;
@@ -216,6 +202,75 @@ __device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32
   if (lane < NGRP) scnt[q * NGRP + lane] = 0;
 }
 
+// End of the split: cut the lists of queries q0..q0+3 to their k best.  The accumulators are dead
+// here, so the 4 x 9 chunk loads of the four queries are all issued before any is used (one
+// memory latency per batch instead of one per chunk); entries below the query's final certified
+// threshold are dropped before ranking.
+__device__ __forceinline__ void tail_compact4(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int q0, int k, int lane,
+                                              uint64_t* __restrict__ scratch, const float (&thr)[4]) {
+  const int* kcnt = (const int*)(smem + OFF_KCNT);
+  const int* scnt = (const int*)(smem + OFF_SCNT);
+  constexpr int R = QCAP / 64;
+  uint32_t sb[4][R], rw[4][R];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = q0 + u;
+    const uint32_t* lsc = wg_sc + (size_t)q * QCAP;
+    const uint32_t* lrow = wg_row + (size_t)q * QCAP;
+    const int kc = kcnt[q];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = r * 64 + lane;
+      const bool ok = idx < KEPT ? idx < kc : ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
+      sb[u][r] = 0xFF800000u;   // -inf: fails every '>= thr' test below unless thr is -inf ...
+      rw[u][r] = 0xFFFFFFFFu;   // ... in which case this marker row says "not an entry"
+      if (ok) { sb[u][r] = lsc[idx]; rw[u][r] = lrow[idx]; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = q0 + u;
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool valid = rw[u][r] != 0xFFFFFFFFu && __uint_as_float(sb[u][r]) >= thr[u];
+      const unsigned long long bal = __ballot(valid);
+      if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = make_key(sb[u][r], rw[u][r]);
+      total += __popcll(bal);
+    }
+    rank_and_keep(wg_sc + (size_t)q * QCAP, wg_row + (size_t)q * QCAP, q, k, lane, scratch, total);
+  }
+}
+
+__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k,
+                                              int lane, uint64_t* __restrict__ scratch, float keep_thr) {
+  // replay-path compaction of ONE query (register-light: the 128 accumulators are live here)
+  int* kcnt = (int*)(smem + OFF_KCNT);
+  int* scnt = (int*)(smem + OFF_SCNT);
+  const int kc = kcnt[q];
+  int total = 0;
+  {
+#pragma unroll 1
+    for (int r = 0; r < QCAP / 64; ++r) {
+      const int idx = r * 64 + lane;
+      bool valid;
+      if (idx < KEPT) valid = idx < kc;
+      else valid = ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
+      uint64_t key = 0ull;
+      if (valid) {
+        const uint32_t sb = lsc[idx];
+        valid = __uint_as_float(sb) >= keep_thr;        // entries below a certified threshold cannot be in the top k
+        if (valid) key = make_key(sb, lrow[idx]);       // never 0 for a valid entry (row < 2^31)
+      }
+      const unsigned long long bal = __ballot(valid);
+      if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      total += __popcll(bal);
+    }
+  }
+  // (one wave: program order + the LDS queue order make the staged keys visible to every lane)
+  rank_and_keep(lsc, lrow, q, k, lane, scratch, total);
+}
+
 // Owner wave w (queries 32w .. 32w+31) compacts every query that has a segment above `limit`.
 __device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int w, int lane, int k, int limit,
                                               uint64_t* __restrict__ scratch) {
@@ -231,7 +286,7 @@ __device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint
     const int b = __builtin_ctzll(m);
     m &= m - 1;
     const int qq = w * 32 + b;
-    compact_query(wg_sc + (size_t)qq * QCAP, wg_row + (size_t)qq * QCAP, qq, k, lane, scratch);
+    compact_query(wg_sc + (size_t)qq * QCAP, wg_row + (size_t)qq * QCAP, qq, k, lane, scratch, -INFINITY);
   }
 }
 
@@ -581,17 +636,33 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   }
 
   __syncthreads();
-  MRAG_STAMP(99);
-  for (int i = tid; i < TQ * NCNT; i += NTHR) {
-    const int q = i / NCNT, c = i - q * NCNT;
-    p.counts[(size_t)wg * TQ * NCNT + i] = c == 0 ? kcnt[q] : min(scnt[q * NGRP + c - 1], SEG);
+  MRAG_STAMP(98);
+  // ---- end of the split: every query's list is cut to its k best (sorted) so that K4 only has to
+  // merge S x k entries.  Entries below the final certified threshold are dropped before ranking
+  // (typically ~25 of ~170 survive), which is what keeps this tail at ~1 % of the workgroup's time.
+  if (n_tiles > 0) {
+    const uint32_t* stat_last = stat + ((n_tiles - 1) & 1) * TQ;
+    uint64_t* scratch = (uint64_t*)(smem + w * 8192);
+    for (int qq = 0; qq < 32; qq += 4) {
+      float thr_f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = w * 32 + qq + u;
+        thr_f[u] = tau_c[q];
+        if (p.k <= K_CERT) thr_f[u] = fmaxf(thr_f[u], ord_f32(stat_last[q]));
+      }
+      tail_compact4(wg_sc, wg_row, w * 32 + qq, p.k, lane, scratch, thr_f);
+    }
   }
+  __syncthreads();
+  MRAG_STAMP(99);
+  if (tid < TQ) p.counts[(size_t)wg * TQ + tid] = kcnt[tid];
 }
 
 // ------------------------------------------------------------------------------------------
 // K4: one wave per query selects the k best of the S workgroups' lists (kept + 8 segments each).
 // ------------------------------------------------------------------------------------------
-constexpr int MERGE_LDS_ENT = 8192;   // 64 KiB of keys per workgroup
+constexpr int MERGE_LDS_ENT = 4096 + 64;   // >= 64 regions x KMAX entries + the carried best
 
 struct MergeParams {
   const uint32_t* list_sc;
@@ -634,9 +705,9 @@ __device__ __forceinline__ int merge_extract(const uint64_t* keys, int fill, int
   return nsel;
 }
 
-// One wave per query.  The query's candidates sit in S x 9 regions (kept area + 8 lane segments
-// per K2 workgroup); 64 regions are gathered at a time, one region per lane, into LDS at offsets
-// from a wave prefix sum, then the k best are extracted by k wave-wide max passes.
+// One wave per query.  Every K2 workgroup left the query's k best (sorted) in its kept area; 64
+// of them are gathered at a time, one per lane, into LDS at offsets from a wave prefix sum, then
+// the k best are extracted by k wave-wide max passes.
 __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   __shared__ uint64_t keys[MERGE_LDS_ENT];
   __shared__ uint64_t best[KMAX];
@@ -645,26 +716,24 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   if (q >= p.nq) return;
   const int t = (int)(q / TQ), ql = (int)(q % TQ);
   const int k = p.k;
-  const int n_groups = p.pair_loc ? p.nprobe : p.S;
-  const int n_regions = n_groups * NCNT;
+  const int n_regions = p.pair_loc ? p.nprobe : p.S;   // one region (the kept area, <= k entries) per K2 workgroup
   int fill = 0;
   for (int r0 = 0; r0 < n_regions; r0 += 64) {
     const int r = r0 + lane;
     int c = 0;
     size_t base = 0;
     if (r < n_regions) {
-      const int s = r / NCNT, part = r - s * NCNT;
       size_t wq;
       bool ok = true;
       if (p.pair_loc) {
-        const int2 loc = p.pair_loc[q * p.nprobe + s];
+        const int2 loc = p.pair_loc[q * p.nprobe + r];
         ok = loc.x >= 0;
         wq = (size_t)(ok ? loc.x : 0) * TQ + (size_t)loc.y;
       } else {
-        wq = (size_t)(t * p.S + s) * TQ + ql;
+        wq = (size_t)(t * p.S + r) * TQ + ql;
       }
-      if (ok) c = p.counts[wq * NCNT + part];
-      base = wq * QCAP + (part == 0 ? 0 : KEPT + (part - 1) * SEG);
+      if (ok) c = p.counts[wq];
+      base = wq * QCAP;
     }
     int incl = c;   // inclusive wave prefix sum
 #pragma unroll
@@ -815,7 +884,7 @@ int bf_launch(const BfLaunch& a) {
     // ---- descriptor mode: one launch, one merge -------------------------------------------
     const size_t grid = (size_t)a.n_wg;
     MRAG_TRY(a.lists->ensure(grid * TQ * QCAP * 8));
-    MRAG_TRY(a.counts->ensure(grid * TQ * NCNT * sizeof(int)));
+    MRAG_TRY(a.counts->ensure(grid * TQ * sizeof(int)));
     p.queries = a.queries;
     p.n_rows = 0; p.n_ctiles = 0; p.nq = 0; p.T = (int)grid; p.S = 1; p.xcd_map = 0;
     p.wg_desc = a.wg_desc;
@@ -850,7 +919,7 @@ int bf_launch(const BfLaunch& a) {
     choose_split(T, n_ctiles, &S, &xcd);
     const size_t grid = (size_t)T * S;
     MRAG_TRY(a.lists->ensure(grid * TQ * QCAP * 8));
-    MRAG_TRY(a.counts->ensure(grid * TQ * NCNT * sizeof(int)));
+    MRAG_TRY(a.counts->ensure(grid * TQ * sizeof(int)));
     p.queries = a.queries + (size_t)q0 * a.ld;
     p.n_rows = (int)a.n_rows;
     p.n_ctiles = n_ctiles;
