@@ -95,8 +95,7 @@ struct BfParams {
                             // first tile, end tile, end row, 0,0,0}; NULL = dense (t, s) decomposition
   int dbg;                  // development ablations (MRAG_DEBUG_FLAGS); 0 in production
   long long* stamps;        // dbg & 16: block 0 / wave 0 writes s_memtime stamps here
-  uint32_t* list_sc;        // [T*S][256][QCAP]  score bits   (SoA: two dword stores per push)
-  uint32_t* list_row;       // [T*S][256][QCAP]  local row
+  uint2* list;              // [T*S][256][QCAP]  {score bits, local row}: one 8-byte store per push
   int* counts;              // [T*S][256] entries left in the kept area
 };
 
@@ -136,10 +135,10 @@ template <> struct Mfma<MRAG_BF16> {
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-// LDS accesses of the epilogue's hot path go through inline asm: with LDS-DMA prefetches in
-// flight hipcc guards every ordinary LDS access with s_waitcnt vmcnt(0) (it cannot prove the
-// DMA writes a different LDS region), which would drain the next stage's prefetch -- and every
-// outstanding list store -- once per access.  These wait on lgkmcnt only.
+// Note on waits: the LDS-DMA stage loads are issued from inline asm, so hipcc does not know an
+// LDS write is pending on the VM counter and ordinary LDS accesses in the epilogue get lgkmcnt
+// waits only (with the __builtin_amdgcn_global_load_lds form every LDS access was guarded by
+// s_waitcnt vmcnt(0), draining the prefetch and every outstanding list store per access).
 __device__ __forceinline__ uint32_t lds_off(const void* p) {
   return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -179,7 +178,7 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 // kernel's 256-VGPR budget with the 128 accumulators); slow, and rare by construction.
 
 // Rank the `total` keys staged in `scratch` and write the k best (sorted) into the kept area.
-__device__ __forceinline__ void rank_and_keep(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k, int lane,
+__device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, int k, int lane,
                                               const uint64_t* __restrict__ scratch, int total) {
   float* tau_c = (float*)(smem + OFF_TAU);
   int* kcnt = (int*)(smem + OFF_KCNT);
@@ -193,8 +192,7 @@ __device__ __forceinline__ void rank_and_keep(uint32_t* __restrict__ lsc, uint32
     for (int j = 0; j < total; ++j) rank += (scratch[j] > my) ? 1 : 0;
     if (i < total && rank < k) {
       const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
-      lsc[rank] = sb;
-      lrow[rank] = 0xFFFFFFFFu - (uint32_t)my;
+      lst[rank] = make_uint2(sb, 0xFFFFFFFFu - (uint32_t)my);
       if (rank == k - 1) tau_c[q] = __uint_as_float(sb);
     }
   }
@@ -206,7 +204,7 @@ __device__ __forceinline__ void rank_and_keep(uint32_t* __restrict__ lsc, uint32
 // here, so the 4 x 9 chunk loads of the four queries are all issued before any is used (one
 // memory latency per batch instead of one per chunk); entries below the query's final certified
 // threshold are dropped before ranking.
-__device__ __forceinline__ void tail_compact4(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int q0, int k, int lane,
+__device__ __forceinline__ void tail_compact4(uint2* __restrict__ wg_list, int q0, int k, int lane,
                                               uint64_t* __restrict__ scratch, const float (&thr)[4]) {
   const int* kcnt = (const int*)(smem + OFF_KCNT);
   const int* scnt = (const int*)(smem + OFF_SCNT);
@@ -215,8 +213,7 @@ __device__ __forceinline__ void tail_compact4(uint32_t* __restrict__ wg_sc, uint
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int q = q0 + u;
-    const uint32_t* lsc = wg_sc + (size_t)q * QCAP;
-    const uint32_t* lrow = wg_row + (size_t)q * QCAP;
+    const uint2* lst = wg_list + (size_t)q * QCAP;
     const int kc = kcnt[q];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -224,7 +221,7 @@ __device__ __forceinline__ void tail_compact4(uint32_t* __restrict__ wg_sc, uint
       const bool ok = idx < KEPT ? idx < kc : ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
       sb[u][r] = 0xFF800000u;   // -inf: fails every '>= thr' test below unless thr is -inf ...
       rw[u][r] = 0xFFFFFFFFu;   // ... in which case this marker row says "not an entry"
-      if (ok) { sb[u][r] = lsc[idx]; rw[u][r] = lrow[idx]; }
+      if (ok) { const uint2 e = lst[idx]; sb[u][r] = e.x; rw[u][r] = e.y; }
     }
   }
 #pragma unroll
@@ -238,11 +235,11 @@ __device__ __forceinline__ void tail_compact4(uint32_t* __restrict__ wg_sc, uint
       if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = make_key(sb[u][r], rw[u][r]);
       total += __popcll(bal);
     }
-    rank_and_keep(wg_sc + (size_t)q * QCAP, wg_row + (size_t)q * QCAP, q, k, lane, scratch, total);
+    rank_and_keep(wg_list + (size_t)q * QCAP, q, k, lane, scratch, total);
   }
 }
 
-__device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32_t* __restrict__ lrow, int q, int k,
+__device__ __forceinline__ void compact_query(uint2* __restrict__ lst, int q, int k,
                                               int lane, uint64_t* __restrict__ scratch, float keep_thr) {
   // replay-path compaction of ONE query (register-light: the 128 accumulators are live here)
   int* kcnt = (int*)(smem + OFF_KCNT);
@@ -258,9 +255,9 @@ __device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32
       else valid = ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
       uint64_t key = 0ull;
       if (valid) {
-        const uint32_t sb = lsc[idx];
-        valid = __uint_as_float(sb) >= keep_thr;        // entries below a certified threshold cannot be in the top k
-        if (valid) key = make_key(sb, lrow[idx]);       // never 0 for a valid entry (row < 2^31)
+        const uint2 e = lst[idx];
+        valid = __uint_as_float(e.x) >= keep_thr;       // entries below a certified threshold cannot be in the top k
+        if (valid) key = make_key(e.x, e.y);            // never 0 for a valid entry (row < 2^31)
       }
       const unsigned long long bal = __ballot(valid);
       if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = key;
@@ -268,11 +265,11 @@ __device__ __forceinline__ void compact_query(uint32_t* __restrict__ lsc, uint32
     }
   }
   // (one wave: program order + the LDS queue order make the staged keys visible to every lane)
-  rank_and_keep(lsc, lrow, q, k, lane, scratch, total);
+  rank_and_keep(lst, q, k, lane, scratch, total);
 }
 
 // Owner wave w (queries 32w .. 32w+31) compacts every query that has a segment above `limit`.
-__device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint32_t* __restrict__ wg_row, int w, int lane, int k, int limit,
+__device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_list, int w, int lane, int k, int limit,
                                               uint64_t* __restrict__ scratch) {
   const int* scnt = (const int*)(smem + OFF_SCNT);
   const int q = w * 32 + (lane & 31);
@@ -286,7 +283,7 @@ __device__ __forceinline__ void compact_owned(uint32_t* __restrict__ wg_sc, uint
     const int b = __builtin_ctzll(m);
     m &= m - 1;
     const int qq = w * 32 + b;
-    compact_query(wg_sc + (size_t)qq * QCAP, wg_row + (size_t)qq * QCAP, qq, k, lane, scratch, -INFINITY);
+    compact_query(wg_list + (size_t)qq * QCAP, qq, k, lane, scratch, -INFINITY);
   }
 }
 
@@ -340,8 +337,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
     rows_end = p.n_rows;
   }
-  uint32_t* wg_sc = p.list_sc + (size_t)wg * TQ * QCAP;
-  uint32_t* wg_row = p.list_row + (size_t)wg * TQ * QCAP;
+  uint2* wg_list = p.list + (size_t)wg * TQ * QCAP;
   const int ksteps = p.ksteps;
 
   float* tau_c = (float*)(smem + OFF_TAU);
@@ -499,8 +495,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
                 m2 = fmaxf(m2, fminf(m1, v));
                 m1 = fmaxf(m1, v);
               }
-            lds_store_u32(&rm[(nf * 2 + 0) * NTHR + tid], __float_as_uint(m1));
-            lds_store_u32(&rm[(nf * 2 + 1) * NTHR + tid], __float_as_uint(m2));
+            rm[(nf * 2 + 0) * NTHR + tid] = __float_as_uint(m1);
+            rm[(nf * 2 + 1) * NTHR + tid] = __float_as_uint(m2);
             float x = m2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
@@ -509,7 +505,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           __syncthreads();
           MRAG_STAMP(11);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(lds_load_u32(&stat_cur[q0 + nf * 16])));
+          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
         } else {
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) thr[nf] = -INFINITY;
@@ -517,8 +513,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       } else {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          const float sc = certify ? ord_f32(lds_load_u32(&stat_prev[q0 + nf * 16])) : -INFINITY;
-          thr[nf] = fmaxf(sc, __uint_as_float(lds_load_u32(&tau_c[q0 + nf * 16])));
+          const float sc = certify ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
+          thr[nf] = fmaxf(sc, tau_c[q0 + nf * 16]);
         }
       }
 #pragma unroll
@@ -526,7 +522,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         if (q0 + nf * 16 >= nq_local) thr[nf] = INFINITY;   // padding queries never list anything
       int cseg[4];   // this lane's segment fill, per query column
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) cseg[nf] = (int)lds_load_u32(&scnt[(q0 + nf * 16) * NGRP + grp]);
+      for (int nf = 0; nf < 4; ++nf) cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
       MRAG_STAMP(21);
 
       // ---- push: attempt 0 = whole tile at once; a full segment -> replay in 4 sub-rounds ------
@@ -542,8 +538,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         for (int nf = 0; nf < 4; ++nf) {
           const int q = q0 + nf * 16;
           const size_t seg0 = (size_t)q * QCAP + KEPT + grp * SEG;
-          uint32_t* lsc = wg_sc + seg0;
-          uint32_t* lrow = wg_row + seg0;
+          uint2* lst = wg_list + seg0;
           float tm = -INFINITY;
           int c = cseg[nf];
 #pragma unroll
@@ -557,8 +552,9 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
             for (int j = 0; j < 4; ++j) {
               if (a[j] > thr[nf]) {
                 if (c < SEG) {
-                  lsc[c] = __float_as_uint(a[j]);
-                  lrow[c] = (uint32_t)(rbase + mf * 16 + j);
+                  uint32_t sv = __float_as_uint(a[j]);
+                  asm volatile("" : "+v"(sv));   // form the {score,row} pair HERE, not hoisted out of the tile loop (spills)
+                  lst[c] = make_uint2(sv, (uint32_t)(rbase + mf * 16 + j));
                 }
                 ++c;
               }
@@ -573,11 +569,11 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           // fold this tile's maxima into the running certificate used from the NEXT tile on
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {
-            const float o1 = __uint_as_float(lds_load_u32(&rm[(nf * 2 + 0) * NTHR + tid]));
-            const float o2 = __uint_as_float(lds_load_u32(&rm[(nf * 2 + 1) * NTHR + tid]));
+            const float o1 = __uint_as_float(rm[(nf * 2 + 0) * NTHR + tid]);
+            const float o2 = __uint_as_float(rm[(nf * 2 + 1) * NTHR + tid]);
             const float n2 = fmaxf(o2, fminf(o1, tmax[nf])), n1 = fmaxf(o1, tmax[nf]);
-            lds_store_u32(&rm[(nf * 2 + 0) * NTHR + tid], __float_as_uint(n1));
-            lds_store_u32(&rm[(nf * 2 + 1) * NTHR + tid], __float_as_uint(n2));
+            rm[(nf * 2 + 0) * NTHR + tid] = __float_as_uint(n1);
+            rm[(nf * 2 + 1) * NTHR + tid] = __float_as_uint(n2);
             float x = n2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
@@ -610,7 +606,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         }
         // replay step: make room (every segment <= SEG - 8), then reload counts and thresholds
         // LDS scratch: the stage buffer this K step has just consumed (free until the next stage() call)
-        compact_owned(wg_sc, wg_row, w, elane, p.k, SEG - 8, (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192));
+        compact_owned(wg_list, w, elane, p.k, SEG - 8, (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192));
         __syncthreads();
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -651,7 +647,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         thr_f[u] = tau_c[q];
         if (p.k <= K_CERT) thr_f[u] = fmaxf(thr_f[u], ord_f32(stat_last[q]));
       }
-      tail_compact4(wg_sc, wg_row, w * 32 + qq, p.k, lane, scratch, thr_f);
+      tail_compact4(wg_list, w * 32 + qq, p.k, lane, scratch, thr_f);
     }
   }
   __syncthreads();
@@ -665,8 +661,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 constexpr int MERGE_LDS_ENT = 4096 + 64;   // >= 64 regions x KMAX entries + the carried best
 
 struct MergeParams {
-  const uint32_t* list_sc;
-  const uint32_t* list_row;
+  const uint2* list;
   const int* counts;
   int T, S, k;
   int64_t nq;
@@ -751,9 +746,10 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
     }
     const int off0 = fill + incl - c;
     for (int i = 0; i < c; ++i) {
-      uint32_t row = p.list_row[base + i];
+      const uint2 e = p.list[base + i];
+      uint32_t row = e.y;
       if (p.row_ids) row = (uint32_t)p.row_ids[row];
-      keys[off0 + i] = make_key(p.list_sc[base + i], row);
+      keys[off0 + i] = make_key(e.x, row);
     }
     fill += total;
   }
@@ -888,8 +884,7 @@ int bf_launch(const BfLaunch& a) {
     p.queries = a.queries;
     p.n_rows = 0; p.n_ctiles = 0; p.nq = 0; p.T = (int)grid; p.S = 1; p.xcd_map = 0;
     p.wg_desc = a.wg_desc;
-    p.list_sc = (uint32_t*)a.lists->p;
-    p.list_row = p.list_sc + grid * TQ * QCAP;
+    p.list = (uint2*)a.lists->p;
     p.counts = (int*)a.counts->p;
     if (grid) {
       if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
@@ -898,7 +893,7 @@ int bf_launch(const BfLaunch& a) {
     }
     if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
     MergeParams mp;
-    mp.list_sc = p.list_sc; mp.list_row = p.list_row; mp.counts = p.counts;
+    mp.list = p.list; mp.counts = p.counts;
     mp.T = 0; mp.S = 0; mp.k = a.k; mp.nq = a.nq; mp.id_base = a.id_base;
     mp.pair_loc = (const int2*)a.pair_loc; mp.nprobe = a.nprobe; mp.row_ids = a.row_ids;
     mp.out_scores = a.out_scores; mp.out_ids = a.out_ids;
@@ -926,15 +921,14 @@ int bf_launch(const BfLaunch& a) {
     p.nq = (int)nq;
     p.T = T; p.S = S; p.xcd_map = xcd;
     p.wg_desc = nullptr;
-    p.list_sc = (uint32_t*)a.lists->p;
-    p.list_row = p.list_sc + grid * TQ * QCAP;
+    p.list = (uint2*)a.lists->p;
     p.counts = (int*)a.counts->p;
     if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
     else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
     MRAG_HIP(hipGetLastError());
     if (t0 + MAX_QTILES_PER_LAUNCH >= T_all && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
     MergeParams mp;
-    mp.list_sc = p.list_sc; mp.list_row = p.list_row; mp.counts = p.counts;
+    mp.list = p.list; mp.counts = p.counts;
     mp.T = T; mp.S = S; mp.k = a.k; mp.nq = nq; mp.id_base = a.id_base;
     mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
     mp.out_scores = a.out_scores + (size_t)q0 * a.k;
