@@ -154,6 +154,11 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(lds_off(p)), "v"(x) : "memory");
 }
 
+// cache policy of the corpus-stream LDS-DMA loads ("" = default, " nt" = non-temporal); experiment knob
+#ifndef MRAG_A_POLICY
+#define MRAG_A_POLICY ""
+#endif
+
 // Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG build (make DIAG=1);
 // the production kernel carries none of them.
 #ifdef MRAG_DIAG
@@ -377,10 +382,10 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+        "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" MRAG_A_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" MRAG_A_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" MRAG_A_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6" MRAG_A_POLICY "\n\t"
         "s_add_u32 m0, m0, 0x7400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
         "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"

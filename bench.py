@@ -145,6 +145,15 @@ def main():
             "cpu_baseline": None,
             "recall_at_10": None,
         }
+        # HBM-side traffic of K2 comes from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/r01_pmc_traffic.json)
+        pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if world == 1 and (n, nq, d) == (N_CORPUS, N_QUERIES, DIM) and pmc.exists():
+            try:
+                out["roofline"]["traffic"] = json.loads(pmc.read_text())["kernels"]["bf_gemm_topk"]["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes/launch, L2<->fabric requests (Infinity-Cache hits included); profiles/r01_pmc_traffic.json"
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu:
             from oracle import dense_search as ods
             c32 = sh.index.rows()                                  # the stored fp16 bits, as fp32
@@ -159,7 +168,7 @@ def main():
             threads = torch.get_num_threads()
             q32 = q16.astype(np.float32)
             t1 = time.perf_counter(); ods.brute_force_topk_f32(q32[:16], c32, k); probe = time.perf_counter() - t1
-            ns = int(min(1024, max(16, 10.0 / max(probe / 16, 1e-6))))
+            ns = int(min(nq, max(16, 15.0 / max(probe / 16, 1e-6))))       # ~15 s of CPU work
             t1 = time.perf_counter(); ods.brute_force_topk_f32(q32[:ns], c32, k); cpu_s = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "queries/s", "cores": os.cpu_count(),
                                    "kind": "port", "blas_threads": threads,
