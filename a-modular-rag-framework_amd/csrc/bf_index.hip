@@ -90,7 +90,7 @@ struct BfParams {
   int T;                    // query tiles
   int S;                    // corpus splits
   int k;
-  int xcd_map;              // 1: S % 8 == 0, use the XCD-aware block -> (t, s) map
+  int xcd_map;              // 0: plain map; else S % 8 == 0 and this many query tiles share an XCD at a time
   const int* wg_desc;       // descriptor mode (IVF list scan): per workgroup {query row0, valid queries,
                             // first tile, end tile, end row, 0,0,0}; NULL = dense (t, s) decomposition
   int dbg;                  // development ablations (MRAG_DEBUG_FLAGS); 0 in production
@@ -315,21 +315,22 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     int t, s;
     const int b = blockIdx.x;
     if (p.xcd_map) {
+      const int QG = p.xcd_map;                       // query tiles that run together on one XCD
       const int x = b & 7, idx = b >> 3, sx = p.S >> 3;
-      const int full = (p.T >> 3) * sx * 8;
+      const int full = (p.T / QG) * sx * QG;
       int g, j, tl;
       if (idx < full) {
-        g = idx / (sx * 8);
-        const int rem = idx - g * (sx * 8);
-        j = rem >> 3;
-        tl = rem & 7;
+        g = idx / (sx * QG);
+        const int rem = idx - g * (sx * QG);
+        j = rem / QG;
+        tl = rem - j * QG;
       } else {
-        const int sz = p.T & 7, r2 = idx - full;
-        g = p.T >> 3;
+        const int sz = p.T % QG, r2 = idx - full;
+        g = p.T / QG;
         j = r2 / sz;
         tl = r2 - j * sz;
       }
-      t = g * 8 + tl;
+      t = g * QG + tl;
       s = x + 8 * j;
     } else {
       s = b % p.S;
@@ -834,13 +835,19 @@ static int grow_rows(BfIndex* ix, int64_t need_rows, hipStream_t stream) {
 // choose the corpus split count for T query tiles
 static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
   if (n_ctiles < 8) { *S_out = std::max(1, n_ctiles); *xcd_out = 0; return; }
+  static int qg = 0, smul = 0;
+  if (!qg) {   // tuning knobs (defaults chosen from measurements)
+    const char* e = getenv("MRAG_QG"); qg = e ? atoi(e) : 8; if (qg != 4 && qg != 8 && qg != 2 && qg != 16) qg = 8;
+    const char* m = getenv("MRAG_SMUL"); smul = m ? atoi(m) : 1; if (smul < 1) smul = 1;
+  }
   int g = T, b = 256;
   while (b) { int r = g % b; g = b; b = r; }   // gcd(T, 256)
   int S = 256 / g;
   if (S < 8) S = 8;
+  S *= smul;
   if (S > n_ctiles) S = (n_ctiles / 8) * 8;
   *S_out = S;
-  *xcd_out = 1;
+  *xcd_out = qg;
 }
 
 
