@@ -399,38 +399,43 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   std::vector<int64_t> probes((size_t)nq * nprobe);
   MRAG_HIP(hipMemcpyAsync(probes.data(), ix->tmp_id.p, probes.size() * 8, hipMemcpyDeviceToHost, stream));
   MRAG_HIP(hipStreamSynchronize(stream));
-  // 2) host: list -> the queries that probe it, cut into workgroups of <= 256 queries
-  std::vector<std::vector<int>> by_list(ix->nlist);
-  for (int64_t q = 0; q < nq; ++q)
+  // 2) host: list -> the queries that probe it (counting sort), cut into workgroups of <= 256 queries
+  const size_t npairs = (size_t)nq * nprobe;
+  std::vector<int> lcount(ix->nlist + 1, 0);
+  for (size_t i = 0; i < npairs; ++i) {
+    const int64_t l = probes[i];
+    if (l >= 0 && ix->list_count[l] > 0) ++lcount[l + 1];
+  }
+  std::vector<int> wg_first(ix->nlist + 1, 0);     // first workgroup of each list
+  for (int l = 0; l < ix->nlist; ++l) wg_first[l + 1] = wg_first[l] + (lcount[l + 1] + 255) / 256;
+  const int n_wg = wg_first[ix->nlist];
+  std::vector<int> desc((size_t)n_wg * 8, 0);      // 8 ints per workgroup
+  std::vector<int64_t> gq((size_t)n_wg * 256, -1); // query row feeding each of the 256 slots (-1 = zero row)
+  std::vector<int> ploc(npairs * 2, 0);
+  for (size_t i = 0; i < npairs; ++i) ploc[2 * i] = -1;
+  std::vector<int> cursor(ix->nlist, 0);
+  for (int64_t q = 0; q < nq; ++q)                 // queries ascend inside every list -> deterministic slots
     for (int pi = 0; pi < nprobe; ++pi) {
-      const int64_t l = probes[(size_t)q * nprobe + pi];
-      if (l >= 0 && ix->list_count[l] > 0) by_list[l].push_back((int)q);
+      const size_t i = (size_t)q * nprobe + pi;
+      const int64_t l = probes[i];
+      if (l < 0 || ix->list_count[l] == 0) continue;
+      const int pos = cursor[l]++;
+      const int wgi = wg_first[l] + (pos >> 8), slot = pos & 255;
+      gq[(size_t)wgi * 256 + slot] = q;
+      ploc[2 * i] = wgi;
+      ploc[2 * i + 1] = slot;
     }
-  std::vector<int> desc;            // 8 ints per workgroup
-  std::vector<int64_t> gq;          // query row feeding each of the 256 slots of every workgroup (-1 = zero row)
-  std::vector<int> ploc((size_t)nq * nprobe * 2, -1);
-  std::vector<int> fill_pi((size_t)nq, 0);
-  // (pair_loc is indexed by the query's probe ORDER; recover it while walking the lists)
-  std::vector<int> probe_slot((size_t)nq * nprobe, -1);
-  int n_wg = 0;
   for (int l = 0; l < ix->nlist; ++l) {
-    const auto& qs = by_list[l];
-    for (size_t c0 = 0; c0 < qs.size(); c0 += 256) {
-      const int cnt = (int)std::min<size_t>(256, qs.size() - c0);
-      desc.insert(desc.end(), {n_wg * 256, cnt, ix->list_tile_lo[l], ix->list_tile_lo[l] + (ix->list_count[l] + 255) / 256,
-                               ix->list_tile_lo[l] * 256 + ix->list_count[l], 0, 0, 0});
-      for (int i = 0; i < 256; ++i) gq.push_back(i < cnt ? (int64_t)qs[c0 + i] : -1);
-      for (int i = 0; i < cnt; ++i) {
-        const int q = qs[c0 + i];
-        int pi = 0;
-        while (probes[(size_t)q * nprobe + pi] != l) ++pi;          // nprobe <= 64
-        ploc[((size_t)q * nprobe + pi) * 2] = n_wg;
-        ploc[((size_t)q * nprobe + pi) * 2 + 1] = i;
-      }
-      ++n_wg;
+    const int cnt_l = lcount[l + 1];
+    for (int c0 = 0, wgi = wg_first[l]; c0 < cnt_l; c0 += 256, ++wgi) {
+      int* d = &desc[(size_t)wgi * 8];
+      d[0] = wgi * 256;
+      d[1] = std::min(256, cnt_l - c0);
+      d[2] = ix->list_tile_lo[l];
+      d[3] = ix->list_tile_lo[l] + (ix->list_count[l] + 255) / 256;
+      d[4] = ix->list_tile_lo[l] * 256 + ix->list_count[l];
     }
   }
-  for (size_t i = 0; i < ploc.size(); i += 2) if (ploc[i] < 0) ploc[i + 1] = 0;
   // 3) gather queries per workgroup, scan the lists, merge
   MRAG_TRY(ix->ploc.ensure(ploc.size() * 4));
   MRAG_HIP(hipMemcpyAsync(ix->ploc.p, ploc.data(), ploc.size() * 4, hipMemcpyHostToDevice, stream));
