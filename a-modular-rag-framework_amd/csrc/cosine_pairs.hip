@@ -31,9 +31,64 @@ __global__ __launch_bounds__(256) void cosine_f64_kernel(const double* __restric
   }
 }
 
+
+// all pairs: one wave per (i, j >= i) pair block row; n is small (graph sentences, MMR pools)
+__global__ __launch_bounds__(256) void cosine_matrix_f64_kernel(const double* __restrict__ x, int64_t n, int dim,
+                                                                double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n * n) return;
+  const int64_t i = pair / n, j = pair % n;
+  if (j < i) return;
+  const double *a = x + i * (int64_t)dim, *b = x + j * (int64_t)dim;
+  double dot = 0.0, aa = 0.0, bb = 0.0;
+  for (int t = lane; t < dim; t += 64) {
+    const double u = a[t], v = b[t];
+    dot += u * v; aa += u * u; bb += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dot += __shfl_xor(dot, off); aa += __shfl_xor(aa, off); bb += __shfl_xor(bb, off);
+  }
+  if (lane == 0) {
+    const double na = sqrt(aa), nb = sqrt(bb);
+    const double c = (na != 0.0 && nb != 0.0) ? dot / (na * nb) : 0.0;
+    out[i * n + j] = c;
+    out[j * n + i] = c;
+  }
+}
+
 }  // namespace mrag
 
 using namespace mrag;
+
+extern "C" int mrag_cosine_matrix_f64(int device, const double* x, int64_t n, int dim, double* out, int is_device, void* stream_) {
+  if (n < 0 || dim <= 0 || n > 32768) return fail(MRAG_ERR_INVALID, "bad shape n=%lld dim=%d (n <= 32768)", (long long)n, dim);
+  if (n == 0) return MRAG_OK;
+  if (!x || !out) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  MRAG_TRY(use_device(device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const double* dx = x;
+  double* dout = out;
+  void* tmp = nullptr;
+  const size_t xb = (size_t)n * dim * 8, ob = (size_t)n * n * 8;
+  if (!is_device) {
+    MRAG_HIP(hipMalloc(&tmp, xb + ob));
+    if (hipMemcpyAsync(tmp, x, xb, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipFree(tmp); return fail(MRAG_ERR_HIP, "H2D copy failed"); }
+    dx = (const double*)tmp;
+    dout = (double*)((char*)tmp + xb);
+  }
+  hipLaunchKernelGGL(cosine_matrix_f64_kernel, dim3((unsigned)((n * n + 3) / 4)), dim3(256), 0, stream, dx, n, dim, dout);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && !is_device) {
+    e = hipMemcpyAsync(out, dout, ob, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  if (tmp) (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(MRAG_ERR_HIP, "cosine_matrix_f64 failed: %s", hipGetErrorString(e));
+  return MRAG_OK;
+}
+
 
 extern "C" int mrag_cosine_f64(int device, const double* query, const double* cands, int64_t n, int dim,
                                double* out_scores, int is_device, void* stream_) {

@@ -60,6 +60,12 @@ int mrag_device_count(int* out_count);
 int mrag_cosine_f64(int device, const double* query, const double* cands, int64_t n, int dim,
                     double* out_scores, int is_device, void* stream);
 
+/* all-pairs form (SURVEY 8f "next" rows): out[i*n+j] = cosine(x_i, x_j), fp64, same zero-norm rule.
+ * Serves the semantic-edge pass of graph construction (app/modules/graph_construction/
+ * edge_builder.py:146-169: per pair three norms + one dot, edge if sim >= threshold) and the
+ * pairwise term of MMR (app/utils/similarity.py:33-62) in one launch instead of n^2 Python calls. */
+int mrag_cosine_matrix_f64(int device, const double* x, int64_t n, int dim, double* out, int is_device, void* stream);
+
 /* ---- a7 at corpus scale: brute-force cosine / inner-product top-k ----------------
  * Replaces "score every candidate, sort descending, truncate" --
  * retrieval_backend.py:245 + :371-372 (and retrieval_adapter.py:129-131) -- over the

@@ -192,3 +192,25 @@ def test_cosine_f64_matches_reference_formula(golden_dir):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-14)
     assert got[3] == 0.0
     assert (cosine_f64(np.zeros(768), c) == 0).all()
+
+
+def test_pairwise_next_rows_semantic_edges_and_mmr(golden_dir):
+    """SURVEY 8f rows 2 and 4 on the all-pairs kernel: edge_builder's pair rule and similarity.mmr_diversify."""
+    import itertools, json
+    from mrag_amd.pairwise import cosine_matrix, semantic_edges, mmr_diversify
+    from oracle import ref_semantics as rs
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((6, 48))
+    vecs = np.concatenate([base + 0.05 * rng.standard_normal((6, 48)) for _ in range(7)])     # 42 "sentences", clustered
+    vecs[5] = 0
+    s = cosine_matrix(vecs)
+    want = np.array([[rs.cosine(list(a), list(b)) for b in vecs] for a in vecs])
+    np.testing.assert_allclose(s, want, rtol=0, atol=1e-14)
+    edges = semantic_edges(vecs, 0.9)
+    ref_edges = [(i, j) for i, j in itertools.combinations(range(len(vecs)), 2) if want[i, j] >= 0.9]
+    assert [(i, j) for i, j, _ in edges] == ref_edges and len(edges) > 20
+    d = json.loads((golden_dir / "f4_minmax.json").read_text())
+    items = [(i, sc, v) for i, sc, v in d["mmr_items"]]
+    for c in d["mmr"]:
+        sel = mmr_diversify(items, top_k=c["top_k"], lambda_weight=c["lambda"])
+        assert [x[0] for x in sel] == c["selected_ids"]          # == the reference's own selections (fixture F4)
