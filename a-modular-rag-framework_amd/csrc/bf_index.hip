@@ -661,6 +661,195 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   if (tid < TQ) p.counts[(size_t)wg * TQ + tid] = kcnt[tid];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K2s: the online regime (<= 16 queries per call, e.g. the reference's one question at a time).
+// HBM-bound: every corpus byte is read once and the query block rides along, so the structure is
+// a pure stream -- 256-row corpus tiles through a 3-stage LDS ring (2 stages = 68 KiB per CU in
+// flight behind counted vmcnt), scored on MFMA against the 16 queries, and filtered per query by
+// ONE wave per query pair (no atomics): a wave appends the scores that beat the query's running
+// k-th best to a 128-entry LDS list, 64 rows at a time, and compacts the list (rank by counting)
+// when it passes 64.  Algorithmic bytes per launch = N*D*2 (+ 16*D*2).
+// ------------------------------------------------------------------------------------------
+constexpr int SQ = 16;                               // queries per block
+constexpr int S_NST = 3;
+constexpr int S_STAGE = A_BYTES + SQ * BK * 2;       // 32 KiB corpus + 2 KiB queries
+constexpr int S_OFF_SC = S_NST * S_STAGE;            // float [16][260] score tile
+constexpr int S_SC_LD = 260;
+constexpr int S_OFF_LIST = S_OFF_SC + SQ * S_SC_LD * 4;   // uint2 [16][128]
+constexpr int S_LCAP = 128;
+constexpr int S_OFF_CNT = S_OFF_LIST + SQ * S_LCAP * 8;   // int [16]
+constexpr int S_OFF_TAU = S_OFF_CNT + 64;                 // float [16]
+constexpr int S_LDS_TOTAL = S_OFF_TAU + 64;
+
+struct StreamParams {
+  const uint16_t* corpus;
+  const uint16_t* queries;   // [>= 16 rows][ld], rows >= nq are zero
+  int ld, ksteps, n_rows, n_ctiles, nq, S, k;
+  uint2* list;               // K4 layout: [(wg*256 + q)*QCAP + i]
+  int* counts;               // [wg*256 + q]
+};
+
+// one wave: cut query q's LDS list to its k best (sorted), raise tau
+__device__ __forceinline__ void stream_compact(uint2* __restrict__ lst, int* __restrict__ cnt, float* __restrict__ tau, int q, int k, int lane) {
+  const int c = cnt[q];
+  uint2 e[2];
+  uint64_t key[2];
+  int rank[2] = {0, 0};
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = r * 64 + lane;
+    e[r] = i < c ? lst[i] : make_uint2(0u, 0u);
+    key[r] = i < c ? make_key(e[r].x, e[r].y) : 0ull;
+  }
+  for (int j = 0; j < c; ++j) {
+    const uint2 o = lst[j];                       // broadcast read
+    const uint64_t kj = make_key(o.x, o.y);
+    rank[0] += kj > key[0] ? 1 : 0;
+    rank[1] += kj > key[1] ? 1 : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = r * 64 + lane;
+    if (i < c && rank[r] < k) {
+      lst[rank[r]] = e[r];
+      if (rank[r] == k - 1) tau[q] = __uint_as_float(e[r].x);
+    }
+  }
+  if (lane == 0) cnt[q] = min(c, k);
+}
+
+template <int DT>
+__global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p) {
+  typedef typename Mfma<DT>::frag frag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x;
+  const int tile_lo = (int)(((long long)wg * p.n_ctiles) / p.S);
+  const int tile_hi = (int)(((long long)(wg + 1) * p.n_ctiles) / p.S);
+  const int ksteps = p.ksteps, n_tiles = tile_hi - tile_lo;
+  float* sc = (float*)(smem + S_OFF_SC);
+  uint2* lists = (uint2*)(smem + S_OFF_LIST);
+  int* cnt = (int*)(smem + S_OFF_CNT);
+  float* tau = (float*)(smem + S_OFF_TAU);
+  if (tid < SQ) { cnt[tid] = 0; tau[tid] = -INFINITY; }
+
+  const uint32_t row_b = (uint32_t)p.ld * 2u;
+  const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
+  const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);
+  const uint32_t chunk_b = 8u * row_b;
+  const size_t tile_bytes = (size_t)TM * p.ld * 2;
+  const char* q_ptr = (const char*)p.queries + (size_t)(w & 1) * chunk_b;     // every wave (re)loads query chunk w&1
+  const uint32_t voff_q = (w & 1) ? voff_o : voff_e;
+  auto stage = [&](const char* a, const char* b, int slot) {
+    const uint32_t la = (uint32_t)(slot * S_STAGE + (4 * w) * 1024);
+    const uint32_t lb = (uint32_t)(slot * S_STAGE + A_BYTES + (w & 1) * 1024);
+    const char *a1 = a + chunk_b, *a2 = a1 + chunk_b, *a3 = a2 + chunk_b;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+        "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_e), "v"(voff_o), "v"(voff_q), "s"(a), "s"(a1), "s"(a2), "s"(a3), "s"(b), "s"(la), "s"(lb)
+        : "memory", "scc");
+  };
+  const int frow = lane & 15, fsw = frow >> 1;
+  const int a_rd = (w * 32 + frow) * 128;
+  const int b_rd = A_BYTES + frow * 128;
+  const int ph0 = ((lane >> 4) ^ fsw) * 16;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+
+  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(4 * w) * 8 * row_b;
+  int pf_kk = 0, pf_left = n_tiles * ksteps, pf_slot = 0, slot = 0;
+#pragma unroll 1
+  for (int i = 0; i < S_NST - 1; ++i)
+    if (pf_left > 0) {
+      stage(a_tile + pf_kk * (BK * 2), q_ptr + pf_kk * (BK * 2), pf_slot);
+      --pf_left;
+      pf_slot = pf_slot == S_NST - 1 ? 0 : pf_slot + 1;
+      if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+    }
+  __syncthreads();
+  const int total = n_tiles * ksteps;
+  int step = 0;
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    for (int kk = 0; kk < ksteps; ++kk, ++step) {
+      if (step + 1 < total) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // the next stage may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (pf_left > 0) {
+        stage(a_tile + pf_kk * (BK * 2), q_ptr + pf_kk * (BK * 2), pf_slot);
+        --pf_left;
+        pf_slot = pf_slot == S_NST - 1 ? 0 : pf_slot + 1;
+        if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+      }
+      const char* sb = smem + slot * S_STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ph = ks ? (ph0 ^ 64) : ph0;
+        const frag b = *(const frag*)(sb + b_rd + ph);
+        const frag a0 = *(const frag*)(sb + a_rd + ph);
+        const frag a1 = *(const frag*)(sb + a_rd + 2048 + ph);
+        acc[0] = Mfma<DT>::run(a0, b, acc[0]);
+        acc[1] = Mfma<DT>::run(a1, b, acc[1]);
+      }
+      slot = slot == S_NST - 1 ? 0 : slot + 1;
+    }
+    // ---- tile done: scores -> LDS [query][row], then one wave per query pair filters them -------
+    const int tile = tile_lo + ti;
+    const int q = lane & 15;
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = w * 32 + mf * 16 + (lane >> 4) * 4 + j;
+        sc[q * S_SC_LD + r] = (tile * TM + r < p.n_rows) ? acc[mf][j] : -INFINITY;
+      }
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll 1
+    for (int qq = 0; qq < 2; ++qq) {
+      const int qi = 2 * w + qq;
+      if (qi >= p.nq) continue;
+      uint2* lst = lists + qi * S_LCAP;
+#pragma unroll 1
+      for (int c0 = 0; c0 < TM; c0 += 64) {
+        const float v = sc[qi * S_SC_LD + c0 + lane];
+        const bool pass = v > tau[qi];                 // strict: a later tie loses to the rows already listed
+        const unsigned long long bal = __ballot(pass);
+        if (bal) {
+          const int base = cnt[qi];
+          if (pass) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint2(__float_as_uint(v), (uint32_t)(tile * TM + c0 + lane));
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) cnt[qi] = base + __popcll(bal);
+          __builtin_amdgcn_wave_barrier();
+          if (base + __popcll(bal) > S_LCAP - 64) stream_compact(lst, cnt, tau, qi, p.k, lane);
+        }
+      }
+    }
+    __syncthreads();   // score tile free again
+  }
+  // ---- end of the split: k best per query (sorted) into the K4 layout ------------------------
+  for (int qq = 0; qq < 2; ++qq) {
+    const int qi = 2 * w + qq;
+    if (qi >= p.nq) { if (lane == 0 && qi < SQ) p.counts[(size_t)wg * TQ + qi] = 0; continue; }
+    uint2* lst = lists + qi * S_LCAP;
+    stream_compact(lst, cnt, tau, qi, p.k, lane);
+    __builtin_amdgcn_wave_barrier();
+    const int c = cnt[qi];
+    uint2* out = p.list + ((size_t)wg * TQ + qi) * QCAP;
+    for (int i = lane; i < c; i += 64) out[i] = lst[i];
+    if (lane == 0) p.counts[(size_t)wg * TQ + qi] = c;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K4: one wave per query selects the k best of the S workgroups' lists (kept + 8 segments each).
 // ------------------------------------------------------------------------------------------
@@ -915,8 +1104,36 @@ int bf_launch(const BfLaunch& a) {
     }
     return MRAG_OK;
   }
-  // ---- dense mode: (query tile, corpus split) grid, query batches of <= 64 tiles ----------------
   const int n_ctiles = (int)((a.n_rows + TM - 1) / TM);
+  if (a.nq <= SQ && n_ctiles >= 8) {
+    // ---- online regime: HBM-bound streaming kernel (K2s), one workgroup per CU-sized corpus split ----
+    static bool s_attr[2] = {false, false};
+    if (!s_attr[di]) {
+      if (di == 0) MRAG_HIP(hipFuncSetAttribute((const void*)bf_stream_topk_kernel<MRAG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
+      else MRAG_HIP(hipFuncSetAttribute((const void*)bf_stream_topk_kernel<MRAG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
+      s_attr[di] = true;
+    }
+    const int S = std::min(n_ctiles, 256);
+    MRAG_TRY(a.lists->ensure((size_t)S * TQ * QCAP * 8));
+    MRAG_TRY(a.counts->ensure((size_t)S * TQ * sizeof(int)));
+    StreamParams sp;
+    sp.corpus = a.corpus; sp.queries = a.queries; sp.ld = a.ld; sp.ksteps = a.ld / BK;
+    sp.n_rows = (int)a.n_rows; sp.n_ctiles = n_ctiles; sp.nq = (int)a.nq; sp.S = S; sp.k = a.k;
+    sp.list = (uint2*)a.lists->p; sp.counts = (int*)a.counts->p;
+    if (di == 0) hipLaunchKernelGGL((bf_stream_topk_kernel<MRAG_F16>), dim3((unsigned)S), dim3(NTHR), S_LDS_TOTAL, stream, sp);
+    else hipLaunchKernelGGL((bf_stream_topk_kernel<MRAG_BF16>), dim3((unsigned)S), dim3(NTHR), S_LDS_TOTAL, stream, sp);
+    MRAG_HIP(hipGetLastError());
+    if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+    MergeParams mp;
+    mp.list = sp.list; mp.counts = sp.counts;
+    mp.T = 1; mp.S = S; mp.k = a.k; mp.nq = a.nq; mp.id_base = a.id_base;
+    mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
+    mp.out_scores = a.out_scores; mp.out_ids = a.out_ids;
+    hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)a.nq), dim3(64), 0, stream, mp);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  }
+  // ---- dense mode: (query tile, corpus split) grid, query batches of <= 64 tiles ----------------
   const int T_all = (int)((a.nq + TQ - 1) / TQ);
   for (int t0 = 0; t0 < T_all; t0 += MAX_QTILES_PER_LAUNCH) {
     const int T = std::min(MAX_QTILES_PER_LAUNCH, T_all - t0);

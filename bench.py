@@ -116,6 +116,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the online regime (one query per call = the reference's own usage): K2s, HBM-bound
+    online_ms = []
+    for i in range(6):
+        sh.index.search(queries[:1], k)
+        if i:
+            online_ms.append(sh.index.last_timing_ms()[0])
+    fence()
+
     out = None
     if rank == 0:
         n_local = sh.hi - sh.lo
@@ -145,6 +153,11 @@ def main():
             "cpu_baseline": None,
             "recall_at_10": None,
         }
+        on_ms = float(np.median(online_ms))
+        on_bytes = (sh.hi - sh.lo) * d * 2.0 + d * 2.0
+        out["online_roofline"] = {"bound": "hbm", "kernel": "bf_stream_topk_kernel", "workload": "1 query x this rank's rows, k=10",
+                                  "kernel_ms": on_ms, "achieved": on_bytes / (on_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": on_bytes / (on_ms * 1e-3) / 1e9 / 8000.0, "bytes_per_launch": on_bytes}
         # HBM-side traffic of K2 comes from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/r01_pmc_traffic.json)
         pmc = ROOT / "profiles" / "r01_pmc_traffic.json"

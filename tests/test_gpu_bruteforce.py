@@ -214,3 +214,34 @@ def test_pairwise_next_rows_semantic_edges_and_mmr(golden_dir):
     for c in d["mmr"]:
         sel = mmr_diversify(items, top_k=c["top_k"], lambda_weight=c["lambda"])
         assert [x[0] for x in sel] == c["selected_ids"]          # == the reference's own selections (fixture F4)
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(1, 100000, 768, 20), (16, 70001, 384, 10), (5, 9000, 64, 64), (2, 2048, 128, 1)])
+def test_online_regime_streaming_kernel(nq, n, d, k):
+    """<= 16 queries take the HBM-streaming kernel (K2s): same exactness bars."""
+    c16 = ds.normalize_round(ds.make_gaussian(n, d, 77))
+    q16 = ds.normalize_round(ds.make_gaussian(nq, d, 78))
+    _check(_index(c16), q16, c16, k)
+
+
+def test_online_regime_adversarial_and_ties():
+    d, n = 64, 8000
+    u = ds.l2_normalize(ds.make_gaussian(1, d, 9))[0]
+    c = (np.linspace(0.05, 1.0, n, dtype=np.float32)[:, None] * u[None, :]).astype(np.float16)   # every row beats the last
+    q = ds.normalize_round(u[None, :] + 0.01 * ds.make_gaussian(3, d, 10))
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(d, metric="ip")
+    ix.add(c, normalize=False)
+    sc, ids = ix.search(q, 10, normalize=False)
+    rv, ri = ds.brute_force_topk(q, c, 10)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=TOL)
+    assert ds.gap_aware_id_match(ids, sc, ri, rv, tol=TOL)[1] == 0
+    rng = np.random.default_rng(3)
+    ci = rng.integers(-2, 3, size=(5000, 64)).astype(np.float16)                                   # exact integer ties
+    qi = rng.integers(-2, 3, size=(7, 64)).astype(np.float16)
+    ix2 = DenseIndex(64, metric="ip")
+    ix2.add(ci, normalize=False)
+    for k in (1, 10, 33):
+        s2, i2 = ix2.search(qi, k, normalize=False)
+        rv2, ri2 = ds.brute_force_topk(qi, ci, k)
+        assert (i2 == ri2).all() and (s2 == rv2.astype(np.float32)).all()
