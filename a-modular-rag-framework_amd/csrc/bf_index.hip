@@ -68,6 +68,7 @@ constexpr int SEG = 64;                   // private list segment per (query, la
 constexpr int KEPT = 64;                  // compacted entries per query (= largest k)
 constexpr int QCAP = KEPT + NGRP * SEG;   // 576 list entries per (workgroup, query)
 constexpr int KMAX = KEPT;
+constexpr int DENSE_TILES = 8;             // tiles of a split filtered by the mask + LDS path (see the epilogue)
 constexpr int K_CERT = 16;                // k served by the 16-row threshold certificate
 
 constexpr int OFF_TAU = GEMM_LDS;               // float[256]      k-th best after a compaction
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     tile_hi = (int)(((long long)(s + 1) * p.n_ctiles) / p.S);
     rows_end = p.n_rows;
   }
-  uint2* wg_list = p.list + (size_t)wg * TQ * QCAP;
+  uint2* wg_list = p.list + (MRAG_DBG(64) ? (size_t)(wg & 255) : (size_t)wg) * TQ * QCAP;   // diag 64: alias list memory (timing only)
   const int ksteps = p.ksteps;
 
   float* tau_c = (float*)(smem + OFF_TAU);
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       int cseg[4];   // this lane's segment fill, per query column
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
+      if (ti < DENSE_TILES) __builtin_amdgcn_s_barrier();   // every wave is done reading the stage buffer the dense push pass reuses as scratch
       MRAG_STAMP(21);
 
       // ---- push: attempt 0 = whole tile at once; a full segment -> replay in 4 sub-rounds ------
@@ -537,37 +539,77 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       while (true) {
         int rbase = row0;
         asm volatile("" : "+v"(rbase));   // keep the 128 store operands from being pre-formed outside this loop
-        // Two-level filter.  Always: max of each 4-score group (one MFMA accumulator) and a
-        // wave-uniform test against the column's threshold.  Only a group in which some lane
-        // beats its threshold stores entries (compare + two predicated dword stores each).
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          const int q = q0 + nf * 16;
-          const size_t seg0 = (size_t)q * QCAP + KEPT + grp * SEG;
-          uint2* lst = wg_list + seg0;
-          float tm = -INFINITY;
-          int c = cseg[nf];
-#pragma unroll
-          for (int mf = 0; mf < 8; ++mf) {
-            const f32x4 a = acc[mf][nf];
-            const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-            tm = fmaxf(tm, m4);
-            if (attempt && (mf >> 1) != round) continue;      // replay: 2 accumulators (<= 8 pushes/segment) per round
-            if (!__any(m4 > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (a[j] > thr[nf]) {
-                if (c < SEG) {
-                  uint32_t sv = __float_as_uint(a[j]);
-                  asm volatile("" : "+v"(sv));   // form the {score,row} pair HERE, not hoisted out of the tile loop (spills)
-                  lst[c] = make_uint2(sv, (uint32_t)(rbase + mf * 16 + j));
-                }
+        if (ti < DENSE_TILES) {
+          // (a) first tiles of a split: some lane passes in almost every accumulator
+          // Filter, per query column of this lane (32 scores): lane maximum first; when some lane of
+          // the wave beats its threshold, every lane builds a 32-bit pass mask (straight-line code,
+          // no branches), parks its 32 scores in LDS ([accumulator][thread] x 16 B: the stage buffer
+          // the K loop has just consumed) and a short wave-uniform loop stores one passing score per
+          // lane per trip, fetched back from LDS by bit index (registers cannot be indexed at run time).
+          // ~140 instructions per column whatever the pass rate -- the early tiles of a split pass
+          // somewhere in almost every accumulator, which made per-accumulator branching 4x dearer.
+          char* stg = smem + (buf ^ 1) * STAGE_BYTES + tid * 16;
+  #pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            float tm = acc[0][nf][0];
+  #pragma unroll
+            for (int mf = 0; mf < 8; ++mf) tm = fmaxf(tm, fmaxf(fmaxf(acc[mf][nf][0], acc[mf][nf][1]), fmaxf(acc[mf][nf][2], acc[mf][nf][3])));
+            tmax[nf] = tm;
+            if (!__any(tm > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
+            uint32_t pm = 0u;
+  #pragma unroll
+            for (int mf = 7; mf >= 0; --mf)
+  #pragma unroll
+              for (int j = 3; j >= 0; --j) pm = (pm << 1) | (acc[mf][nf][j] > thr[nf] ? 1u : 0u);   // bit = mf*4 + j
+            if (attempt) pm &= 0xFFu << (8 * round);            // replay: 2 accumulators (<= 8 pushes/segment) per round
+  #pragma unroll
+            for (int mf = 0; mf < 8; ++mf) *(f32x4*)(stg + mf * (NTHR * 16)) = acc[mf][nf];
+            const int q = q0 + nf * 16;
+            uint2* lst = wg_list + (size_t)q * QCAP + KEPT + grp * SEG;
+            int c = cseg[nf];
+            while (__any(pm != 0u)) {
+              if (pm) {
+                const int b = __builtin_ctz(pm);
+                pm &= pm - 1u;
+                const float v = *(const float*)(stg + (b >> 2) * (NTHR * 16) + (b & 3) * 4);
+                if (c < SEG) lst[c] = make_uint2(__float_as_uint(v), (uint32_t)(rbase + (b >> 2) * 16 + (b & 3)));
                 ++c;
               }
             }
+            cseg[nf] = c;
           }
-          cseg[nf] = c;
-          tmax[nf] = tm;
+        } else {
+          // (b) later tiles: passes are sparse.  Two-level filter: max of each 4-score group (one MFMA
+          // accumulator) and a wave-uniform test against the column's threshold; only a group in which
+          // some lane beats its threshold runs the store path.
+  #pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            const int q = q0 + nf * 16;
+            uint2* lst = wg_list + (size_t)q * QCAP + KEPT + grp * SEG;
+            float tm = -INFINITY;
+            int c = cseg[nf];
+  #pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+              const f32x4 a = acc[mf][nf];
+              const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+              tm = fmaxf(tm, m4);
+              if (attempt && (mf >> 1) != round) continue;      // replay: 2 accumulators (<= 8 pushes/segment) per round
+              if (!__any(m4 > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (a[j] > thr[nf]) {
+                  if (c < SEG) {
+                    uint32_t sv = __float_as_uint(a[j]);
+                    asm volatile("" : "+v"(sv));   // form the {score,row} pair HERE, not hoisted out of the tile loop (spills)
+                    lst[c] = make_uint2(sv, (uint32_t)(rbase + mf * 16 + j));
+                  }
+                  ++c;
+                }
+              }
+            }
+            cseg[nf] = c;
+            tmax[nf] = tm;
+          }
         }
         if ((cseg[0] > SEG) | (cseg[1] > SEG) | (cseg[2] > SEG) | (cseg[3] > SEG)) lds_store_u32(&flags[0], 1u);
         MRAG_STAMP(22);
