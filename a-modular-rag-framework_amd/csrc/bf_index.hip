@@ -275,12 +275,13 @@ __device__ __forceinline__ void compact_query(uint2* __restrict__ lst, int q, in
 }
 
 // Owner wave w (queries 32w .. 32w+31) compacts every query that has a segment above `limit`.
+template <int QPW>
 __device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_list, int w, int lane, int k, int limit,
                                               uint64_t* __restrict__ scratch) {
   const int* scnt = (const int*)(smem + OFF_SCNT);
-  const int q = w * 32 + (lane & 31);
+  const int q = w * QPW + (lane & (QPW - 1));
   bool need = false;
-  if (lane < 32) {
+  if (lane < QPW) {
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) need |= scnt[q * NGRP + g] > limit;
   }
@@ -288,18 +289,25 @@ __device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_list, int w
   while (m) {
     const int b = __builtin_ctzll(m);
     m &= m - 1;
-    const int qq = w * 32 + b;
+    const int qq = w * QPW + b;
     compact_query(wg_list + (size_t)qq * QCAP, qq, k, lane, scratch, -INFINITY);
   }
 }
 
-template <int DT>
-__global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
+// NF = 16-query column groups per wave: 4 -> 8 waves (2 x 4) of 128 x 64, two per SIMD, 256 VGPRs each;
+//                                        8 -> 4 waves (2 x 2) of 128 x 128, ONE per SIMD, 512 VGPRs each
+template <int DT, int NF>
+__global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_topk_kernel(BfParams p) {
+  constexpr int WN = 16 / NF;            // waves along the query dimension
+  constexpr int NW = 2 * WN;             // waves per workgroup
+  constexpr int NT = 64 * NW;            // threads per workgroup
+  constexpr int CPW = 32 / NW;           // 1-KiB DMA chunks per wave per operand and stage
+  constexpr int QPW = TQ / NW;           // queries whose lists a wave owns (compaction)
   typedef typename Mfma<DT>::frag frag;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WN, wn = w % WN;
 #ifdef MRAG_DIAG
   int stamp_n = 0;
 #endif
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     stat[tid] = 0xFFFFFFFFu;
     stat[TQ + tid] = 0xFFFFFFFFu;
   }
-  for (int i = tid; i < TQ * NGRP; i += NTHR) scnt[i] = 0;
+  for (int i = tid; i < TQ * NGRP; i += NT) scnt[i] = 0;
   if (tid == 0) flags[0] = 0;
 
   // ---- LDS-DMA source offsets: wave w fills 1-KiB chunks 4w..4w+3 of each operand ---------
@@ -370,51 +378,52 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   const uint32_t row_b = (uint32_t)p.ld * 2u;                       // bytes per row
   const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);        // even chunks
   const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);  // odd chunks
-  const char* q_ptr = (const char*)(p.queries + (size_t)q_row0 * p.ld) + (size_t)(4 * w) * 8 * row_b;
+  const char* q_ptr = (const char*)(p.queries + (size_t)q_row0 * p.ld) + (size_t)(CPW * w) * 8 * row_b;
   const size_t tile_bytes = (size_t)TM * p.ld * 2;
   const uint32_t chunk_b = 8u * row_b;                               // 8 rows
 
-  // One stage = 8 LDS-DMA loads per wave (4 corpus chunks, 4 query chunks), issued from inline
-  // asm.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt below.
-  // M0 (LDS destination base) is written inside the statement that uses it and restored after.
+  // One stage = 2*CPW LDS-DMA loads per wave (CPW corpus chunks, CPW query chunks), issued from inline
+  // asm two at a time.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt
+  // below.  M0 (LDS destination base) is written inside the statement that uses it and restored after.
   auto stage = [&](const char* a, const char* b, int buf) {
-    const uint32_t la = (uint32_t)(buf * STAGE_BYTES + (4 * w) * 1024);   // wave-uniform LDS byte address
-    const char *a1 = a + chunk_b, *a2 = a1 + chunk_b, *a3 = a2 + chunk_b;
-    const char *b1 = b + chunk_b, *b2 = b1 + chunk_b, *b3 = b2 + chunk_b;
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" MRAG_A_POLICY "\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" MRAG_A_POLICY "\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" MRAG_A_POLICY "\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6" MRAG_A_POLICY "\n\t"
-        "s_add_u32 m0, m0, 0x7400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %10\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff_e), "v"(voff_o), "s"(a), "s"(a1), "s"(a2), "s"(a3), "s"(b), "s"(b1), "s"(b2), "s"(b3), "s"(la)
-        : "memory", "scc");
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const char* base = op ? b : a;
+#pragma unroll
+      for (int i = 0; i < CPW; i += 2) {
+        const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
+        const char* c0 = base + (size_t)i * chunk_b;
+        const char* c1 = c0 + chunk_b;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
+            : "memory", "scc");
+      }
+    }
   };
 
   // ---- fragment read offsets ------------------------------------------------------------
   const int frow = lane & 15;
   const int fsw = frow >> 1;
   const int a_rd = (wm * 128 + frow) * 128;
-  const int b_rd = A_BYTES + (wn * 64 + frow) * 128;
+  const int b_rd = A_BYTES + (wn * (16 * NF) + frow) * 128;
   const int ph0 = (((lane >> 4)) ^ fsw) * 16;      // k sub-step 0: logical chunks 0..3
   // k sub-step 1 reads logical chunks 4..7: ((4 + x) ^ fsw) * 16 == ph0 ^ 64
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NF];
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // prefetch cursor: (tile, k step) of the NEXT stage to issue, advanced with scalar adds only
   const int n_tiles = tile_hi - tile_lo;
-  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(4 * w) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
+  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(CPW * w) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
   int pf_kk = 0, pf_left = n_tiles * ksteps;
   int buf = 0;
   if (pf_left > 0) {
@@ -439,15 +448,15 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
     for (int ks = 0; ks < 2; ++ks) {
       if (MRAG_DBG(8)) break;   // diag 8: ablate LDS reads + MFMA
       const int ph = ks ? (ph0 ^ 64) : ph0;
-      frag af[8], bfr[4];
+      frag af[8], bfr[NF];
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) af[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph);
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) bfr[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph);
+      for (int nf = 0; nf < NF; ++nf) bfr[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph);
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = Mfma<DT>::run(af[mf], bfr[nf], acc[mf][nf]);
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(af[mf], bfr[nf], acc[mf][nf]);
     }
     buf ^= 1;
 
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
           x += acc[mf][nf][0] + acc[mf][nf][1] + acc[mf][nf][2] + acc[mf][nf][3];
           acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
       int elane = lane;
       asm volatile("" : "+v"(elane));
       const int row0 = tile * TM + wm * 128 + (elane >> 4) * 4;  // + mf*16 + j
-      const int q0 = wn * 64 + (elane & 15);                     // + nf*16
+      const int q0 = wn * (16 * NF) + (elane & 15);              // + nf*16
       const int grp = wm * 4 + (elane >> 4);                     // this lane's segment of each of its queries
       const bool certify = p.k <= K_CERT;
       MRAG_STAMP(10 + (ti == 0 ? 0 : 100));
@@ -481,10 +490,10 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           for (int j = 0; j < 4; ++j)
             if (row0 + mf * 16 + j >= rows_end) {
 #pragma unroll
-              for (int nf = 0; nf < 4; ++nf) acc[mf][nf][j] = -INFINITY;
+              for (int nf = 0; nf < NF; ++nf) acc[mf][nf][j] = -INFINITY;
             }
       }
-      float thr[4];
+      float thr[NF];
       uint32_t* stat_cur = stat + (ti & 1) * TQ;        // certificate built from tiles <= ti
       uint32_t* stat_prev = stat + ((ti & 1) ^ 1) * TQ;  // certificate from tiles < ti
       if (ti == 0) {
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         // IN this tile; >= 16 rows are >= tau0, so pass on '>=' (as '> next_below').
         if (certify) {
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
+          for (int nf = 0; nf < NF; ++nf) {
             float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
             for (int mf = 0; mf < 8; ++mf)
@@ -502,8 +511,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
                 m2 = fmaxf(m2, fminf(m1, v));
                 m1 = fmaxf(m1, v);
               }
-            rm[(nf * 2 + 0) * NTHR + tid] = __float_as_uint(m1);
-            rm[(nf * 2 + 1) * NTHR + tid] = __float_as_uint(m2);
+            rm[(nf * 2 + 0) * NT + tid] = __float_as_uint(m1);
+            rm[(nf * 2 + 1) * NT + tid] = __float_as_uint(m2);
             float x = m2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
@@ -512,30 +521,30 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           __syncthreads();
           MRAG_STAMP(11);
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
+          for (int nf = 0; nf < NF; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
         } else {
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) thr[nf] = -INFINITY;
+          for (int nf = 0; nf < NF; ++nf) thr[nf] = -INFINITY;
         }
       } else {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
           const float sc = certify ? ord_f32(stat_prev[q0 + nf * 16]) : -INFINITY;
           thr[nf] = fmaxf(sc, tau_c[q0 + nf * 16]);
         }
       }
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < NF; ++nf)
         if (q0 + nf * 16 >= nq_local) thr[nf] = INFINITY;   // padding queries never list anything
-      int cseg[4];   // this lane's segment fill, per query column
+      int cseg[NF];   // this lane's segment fill, per query column
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
+      for (int nf = 0; nf < NF; ++nf) cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
       if (ti < DENSE_TILES) __builtin_amdgcn_s_barrier();   // every wave is done reading the stage buffer the dense push pass reuses as scratch
       MRAG_STAMP(21);
 
       // ---- push: attempt 0 = whole tile at once; a full segment -> replay in 4 sub-rounds ------
       int attempt = 0, round = 0;
-      float tmax[4];
+      float tmax[NF];
       while (true) {
         int rbase = row0;
         asm volatile("" : "+v"(rbase));   // keep the 128 store operands from being pre-formed outside this loop
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           // somewhere in almost every accumulator, which made per-accumulator branching 4x dearer.
           char* stg = smem + (buf ^ 1) * STAGE_BYTES + tid * 16;
   #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
+          for (int nf = 0; nf < NF; ++nf) {
             float tm = acc[0][nf][0];
   #pragma unroll
             for (int mf = 0; mf < 8; ++mf) tm = fmaxf(tm, fmaxf(fmaxf(acc[mf][nf][0], acc[mf][nf][1]), fmaxf(acc[mf][nf][2], acc[mf][nf][3])));
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
               for (int j = 3; j >= 0; --j) pm = (pm << 1) | (acc[mf][nf][j] > thr[nf] ? 1u : 0u);   // bit = mf*4 + j
             if (attempt) pm &= 0xFFu << (8 * round);            // replay: 2 accumulators (<= 8 pushes/segment) per round
   #pragma unroll
-            for (int mf = 0; mf < 8; ++mf) *(f32x4*)(stg + mf * (NTHR * 16)) = acc[mf][nf];
+            for (int mf = 0; mf < 8; ++mf) *(f32x4*)(stg + mf * (NT * 16)) = acc[mf][nf];
             const int q = q0 + nf * 16;
             uint2* lst = wg_list + (size_t)q * QCAP + KEPT + grp * SEG;
             int c = cseg[nf];
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
               if (pm) {
                 const int b = __builtin_ctz(pm);
                 pm &= pm - 1u;
-                const float v = *(const float*)(stg + (b >> 2) * (NTHR * 16) + (b & 3) * 4);
+                const float v = *(const float*)(stg + (b >> 2) * (NT * 16) + (b & 3) * 4);
                 if (c < SEG) lst[c] = make_uint2(__float_as_uint(v), (uint32_t)(rbase + (b >> 2) * 16 + (b & 3)));
                 ++c;
               }
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           // accumulator) and a wave-uniform test against the column's threshold; only a group in which
           // some lane beats its threshold runs the store path.
   #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
+          for (int nf = 0; nf < NF; ++nf) {
             const int q = q0 + nf * 16;
             uint2* lst = wg_list + (size_t)q * QCAP + KEPT + grp * SEG;
             float tm = -INFINITY;
@@ -611,17 +620,22 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
             tmax[nf] = tm;
           }
         }
-        if ((cseg[0] > SEG) | (cseg[1] > SEG) | (cseg[2] > SEG) | (cseg[3] > SEG)) lds_store_u32(&flags[0], 1u);
+        {
+          bool over = false;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) over |= cseg[nf] > SEG;
+          if (over) lds_store_u32(&flags[0], 1u);
+        }
         MRAG_STAMP(22);
         if (attempt == 0 && certify && ti != 0) {
           // fold this tile's maxima into the running certificate used from the NEXT tile on
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
-            const float o1 = __uint_as_float(rm[(nf * 2 + 0) * NTHR + tid]);
-            const float o2 = __uint_as_float(rm[(nf * 2 + 1) * NTHR + tid]);
+          for (int nf = 0; nf < NF; ++nf) {
+            const float o1 = __uint_as_float(rm[(nf * 2 + 0) * NT + tid]);
+            const float o2 = __uint_as_float(rm[(nf * 2 + 1) * NT + tid]);
             const float n2 = fmaxf(o2, fminf(o1, tmax[nf])), n1 = fmaxf(o1, tmax[nf]);
-            rm[(nf * 2 + 0) * NTHR + tid] = __float_as_uint(n1);
-            rm[(nf * 2 + 1) * NTHR + tid] = __float_as_uint(n2);
+            rm[(nf * 2 + 0) * NT + tid] = __float_as_uint(n1);
+            rm[(nf * 2 + 1) * NT + tid] = __float_as_uint(n2);
             float x = n2;
             x = fminf(x, __shfl_xor(x, 16));
             x = fminf(x, __shfl_xor(x, 32));
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         if (attempt == 0) {
           if (!flags[0]) {
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];   // commit
+            for (int nf = 0; nf < NF; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];   // commit
             if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;   // becomes stat_cur of tile ti+1
             break;
           }
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
           round = 0;
         } else {
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];     // commit (cannot overflow)
+          for (int nf = 0; nf < NF; ++nf) scnt[(q0 + nf * 16) * NGRP + grp] = cseg[nf];     // commit (cannot overflow)
           if (round == 3) {
             if (tid < TQ) stat_prev[tid] = 0xFFFFFFFFu;
             break;
@@ -654,10 +668,10 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
         }
         // replay step: make room (every segment <= SEG - 8), then reload counts and thresholds
         // LDS scratch: the stage buffer this K step has just consumed (free until the next stage() call)
-        compact_owned(wg_list, w, elane, p.k, SEG - 8, (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192));
+        compact_owned<QPW>(wg_list, w, elane, p.k, SEG - 8, (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192));
         __syncthreads();
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
+        for (int nf = 0; nf < NF; ++nf) {
           cseg[nf] = scnt[(q0 + nf * 16) * NGRP + grp];
           float th = tau_c[q0 + nf * 16];
           if (q0 + nf * 16 >= nq_local) th = INFINITY;
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // The K loop's lane constants may have been spilled around the epilogue.  Touch them HERE so
       // that the compiler's reload (and its s_waitcnt vmcnt, which would also drain the LDS-DMA
       // prefetch it cannot see) sits at the end of the epilogue, not inside the next K step.
@@ -687,15 +701,15 @@ __global__ __launch_bounds__(NTHR, 2) void bf_gemm_topk_kernel(BfParams p) {
   if (n_tiles > 0) {
     const uint32_t* stat_last = stat + ((n_tiles - 1) & 1) * TQ;
     uint64_t* scratch = (uint64_t*)(smem + w * 8192);
-    for (int qq = 0; qq < 32; qq += 4) {
+    for (int qq = 0; qq < QPW; qq += 4) {
       float thr_f[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int q = w * 32 + qq + u;
+        const int q = w * QPW + qq + u;
         thr_f[u] = tau_c[q];
         if (p.k <= K_CERT) thr_f[u] = fmaxf(thr_f[u], ord_f32(stat_last[q]));
       }
-      tail_compact4(wg_list, w * 32 + qq, p.k, lane, scratch, thr_f);
+      tail_compact4(wg_list, w * QPW + qq, p.k, lane, scratch, thr_f);
     }
   }
   __syncthreads();
@@ -1089,16 +1103,29 @@ int64_t bf_round_rows(int64_t n) { return round_up(n, TM); }
 // query) within a few GB: at most 64 query tiles (16 384 queries) per launch.
 constexpr int MAX_QTILES_PER_LAUNCH = 64;
 
+// K2 launcher.  The kernel is templated on the wave tiling; only the 8-wave form (NF = 4) is built:
+// the 4-wave / one-wave-per-SIMD form (NF = 8, 256 accumulator registers per lane) is correct but
+// hipcc's allocation of the 256-AGPR tile spills into the K loop (98 ms vs 13.6 ms, round-1 measurement).
+static int launch_k2(int dtype, size_t grid, hipStream_t stream, const BfParams& p) {
+  static bool attr_done[2] = {false, false};
+  const int di = dtype == MRAG_F16 ? 0 : 1;
+  if (!attr_done[di]) {
+    const void* fn = di == 0 ? (const void*)bf_gemm_topk_kernel<MRAG_F16, 4> : (const void*)bf_gemm_topk_kernel<MRAG_BF16, 4>;
+    MRAG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr_done[di] = true;
+  }
+  if (!grid) return MRAG_OK;
+  const dim3 g((unsigned)grid), b(NTHR);
+  if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16, 4>), g, b, LDS_TOTAL, stream, p);
+  else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16, 4>), g, b, LDS_TOTAL, stream, p);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
 int bf_launch(const BfLaunch& a) {
   if (a.k <= 0 || a.k > KMAX) return fail(MRAG_ERR_UNSUPPORTED, "k = %d outside 1..%d", a.k, KMAX);
   hipStream_t stream = a.stream;
-  static bool attr_done[2] = {false, false};
   const int di = a.dtype == MRAG_F16 ? 0 : 1;
-  if (!attr_done[di]) {
-    if (di == 0) MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    else MRAG_HIP(hipFuncSetAttribute((const void*)bf_gemm_topk_kernel<MRAG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_done[di] = true;
-  }
   BfParams p;
   p.corpus = a.corpus;
   p.ld = a.ld;
@@ -1129,11 +1156,7 @@ int bf_launch(const BfLaunch& a) {
     p.wg_desc = a.wg_desc;
     p.list = (uint2*)a.lists->p;
     p.counts = (int*)a.counts->p;
-    if (grid) {
-      if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-      else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-      MRAG_HIP(hipGetLastError());
-    }
+    MRAG_TRY(launch_k2(a.dtype, grid, stream, p));
     if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
     MergeParams mp;
     mp.list = p.list; mp.counts = p.counts;
@@ -1194,9 +1217,7 @@ int bf_launch(const BfLaunch& a) {
     p.wg_desc = nullptr;
     p.list = (uint2*)a.lists->p;
     p.counts = (int*)a.counts->p;
-    if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-    else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16>), dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
-    MRAG_HIP(hipGetLastError());
+    MRAG_TRY(launch_k2(a.dtype, grid, stream, p));
     if (t0 + MAX_QTILES_PER_LAUNCH >= T_all && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
     MergeParams mp;
     mp.list = p.list; mp.counts = p.counts;
