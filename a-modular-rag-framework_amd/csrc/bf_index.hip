@@ -183,26 +183,81 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 // ranked by counting with broadcast LDS reads.  Register-light on purpose (it shares the
 // kernel's 256-VGPR budget with the 128 accumulators); slow, and rare by construction.
 
-// Rank the `total` keys staged in `scratch` and write the k best (sorted) into the kept area.
+// Select the k best of the `total` unique keys staged in `scratch` (one wave) and write them, sorted
+// best first, into the query's kept area; tau_c rises to the k-th.  MSB-first radix select, 8 bits
+// per pass over an LDS histogram: each pass narrows the bucket that holds the k-th key; it stops as
+// soon as that bucket is needed whole (typically after 3-5 passes).  The <= 64 selected keys are
+// then ranked by counting.  ~600 instructions whatever `total` is (rank-by-counting over all the
+// entries was ~20 000 at 576 entries, which made k > 16 -- no row-count certificate, thresholds
+// driven by compaction alone -- 3-5x slower than k <= 16).
+// scratch layout (8 KiB per wave): keys[QCAP] u64 | hist[256] u32 | sel[KMAX] u64
 __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, int k, int lane,
-                                              const uint64_t* __restrict__ scratch, int total) {
+                                              uint64_t* __restrict__ scratch, int total) {
   float* tau_c = (float*)(smem + OFF_TAU);
   int* kcnt = (int*)(smem + OFF_KCNT);
   int* scnt = (int*)(smem + OFF_SCNT);
-#pragma unroll 1
+  uint32_t* hist = (uint32_t*)(scratch + QCAP);
+  uint64_t* sel = scratch + QCAP + 128;
+  int shift = 64;              // keys with (key >> shift) >= prefix are selected once the loop ends
+  uint64_t prefix = 0ull;
+  if (total > k) {
+    int need = k;
+    for (shift = 56; shift >= 0; shift -= 8) {
+      *(uint4*)&hist[lane * 4] = make_uint4(0u, 0u, 0u, 0u);
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < total; i += 64) {
+        const uint64_t key = scratch[i];
+        const bool active = shift == 56 || (key >> (shift + 8)) == prefix;
+        if (active) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const uint4 h = *(const uint4*)&hist[lane * 4];      // bins 4*lane .. 4*lane+3
+      const int mine = (int)(h.x + h.y + h.z + h.w);
+      int suf = mine;                                       // inclusive suffix sum over lanes >= this one
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_down(suf, off);
+        if (lane + off < 64) suf += v;
+      }
+      int cum = suf - mine;                                 // keys in bins above this lane's
+      int found = -1, above = 0, inb = 0;
+      const int hb[4] = {(int)h.x, (int)h.y, (int)h.z, (int)h.w};
+#pragma unroll
+      for (int b = 3; b >= 0; --b) {
+        if (found < 0 && cum < need && cum + hb[b] >= need) { found = lane * 4 + b; above = cum; inb = hb[b]; }
+        cum += hb[b];
+      }
+      const unsigned long long who = __ballot(found >= 0);
+      const int src = __builtin_ctzll(who);
+      const int digit = __shfl(found, src);
+      above = __shfl(above, src);
+      inb = __shfl(inb, src);
+      need -= above;
+      prefix = (prefix << 8) | (uint64_t)digit;
+      if (inb == need) break;                               // the whole bucket is selected
+    }
+    if (shift < 0) shift = 0;
+  }
+  // gather the selected keys (exactly min(total, k) of them)
+  int nsel = 0;
   for (int base = 0; base < total; base += 64) {
     const int i = base + lane;
-    const uint64_t my = i < total ? scratch[i] : ~0ull;
-    int rank = 0;
-#pragma unroll 4
-    for (int j = 0; j < total; ++j) rank += (scratch[j] > my) ? 1 : 0;
-    if (i < total && rank < k) {
-      const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
-      lst[rank] = make_uint2(sb, 0xFFFFFFFFu - (uint32_t)my);
-      if (rank == k - 1) tau_c[q] = __uint_as_float(sb);
-    }
+    const uint64_t key = i < total ? scratch[i] : 0ull;
+    const bool pick = i < total && (shift >= 64 || (key >> shift) >= prefix);
+    const unsigned long long bal = __ballot(pick);
+    if (pick) sel[nsel + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+    nsel += __popcll(bal);
   }
-  if (lane == 0) kcnt[q] = min(total, k);
+  __builtin_amdgcn_wave_barrier();
+  const uint64_t my = lane < nsel ? sel[lane] : 0ull;
+  int rank = 0;
+  for (int j = 0; j < nsel; ++j) rank += (sel[j] > my) ? 1 : 0;
+  if (lane < nsel) {
+    const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
+    lst[rank] = make_uint2(sb, 0xFFFFFFFFu - (uint32_t)my);
+    if (rank == k - 1) tau_c[q] = __uint_as_float(sb);
+  }
+  if (lane == 0) kcnt[q] = nsel;
   if (lane < NGRP) scnt[q * NGRP + lane] = 0;
 }
 
@@ -676,6 +731,22 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
           float th = tau_c[q0 + nf * 16];
           if (q0 + nf * 16 >= nq_local) th = INFINITY;
           thr[nf] = fmaxf(thr[nf], th);
+        }
+      }
+      if (!certify && ((ti + 1) & ti) == 0 && ti + 1 < n_tiles) {
+        // k > K_CERT has no row-count certificate: thresholds come from compaction alone (tau_c =
+        // the k-th best listed so far).  Compact every query after tiles 0, 1, 3, 7, 15, ... of the
+        // split: each interval then lists ~k entries per query (the rows seen double, the rate of
+        // rows beating a k-th-best threshold halves), so segments practically never fill up.
+        __syncthreads();   // all pushes of this tile are in the lists; nobody still parks scores in the stage buffer
+        // (the accumulators are dead here: the batched-load form used at the end of the split fits)
+        uint64_t* scr = (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192);
+#pragma unroll 1
+        for (int qq = 0; qq < QPW; qq += 4) {
+          float t4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t4[u] = tau_c[w * QPW + qq + u];
+          tail_compact4(wg_list, w * QPW + qq, p.k, elane, scr, t4);
         }
       }
       MRAG_STAMP(14 + (ti == 0 ? 0 : 100));

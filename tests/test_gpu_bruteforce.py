@@ -100,6 +100,33 @@ def test_exact_ties_break_by_row():
         assert (sc == rv.astype(np.float32)).all()
 
 
+@pytest.mark.parametrize("nq,n,d,k", [(300, 40000, 128, 20), (64, 70000, 64, 64), (100, 30000, 96, 33),
+                                      (700, 9000, 64, 30)])
+def test_large_k_batch_compaction_thresholds(nq, n, d, k):
+    """16 < k <= 64 in the batch kernel: no row-count certificate, thresholds come from the
+    scheduled radix-select compactions (after tiles 0, 1, 3, 7, ... of a split)."""
+    c16 = ds.normalize_round(ds.make_gaussian(n, d, 21))
+    q16 = ds.normalize_round(ds.make_gaussian(nq, d, 22))
+    _check(_index(c16), q16, c16, k)
+
+
+def test_large_k_ties_and_identical_rows():
+    rng = np.random.default_rng(4)
+    c = rng.integers(-1, 2, size=(20000, 64)).astype(np.float16)   # few distinct scores: the radix select is decided by row bits
+    q = rng.integers(-1, 2, size=(50, 64)).astype(np.float16)
+    from mrag_amd.index import DenseIndex
+    ix = DenseIndex(64, metric="ip")
+    ix.add(c, normalize=False)
+    for k in (17, 40, 64):
+        sc, ids = ix.search(q, k, normalize=False)
+        rv, ri = ds.brute_force_topk(q, c, k)
+        assert (ids == ri).all()
+        assert (sc == rv.astype(np.float32)).all()
+    same = np.tile(ds.normalize_round(ds.make_gaussian(1, 64, 5)), (5000, 1))
+    sc, ids = _index(same).search(ds.normalize_round(ds.make_gaussian(20, 64, 6)), 40, normalize=False)
+    assert (ids == np.arange(40)[None, :]).all()
+
+
 def test_all_rows_identical():
     c = np.tile(ds.normalize_round(ds.make_gaussian(1, 64, 5)), (3000, 1))
     q = ds.normalize_round(ds.make_gaussian(5, 64, 6))
@@ -110,7 +137,15 @@ def test_all_rows_identical():
 def test_adversarial_increasing_scores_replay_path():
     """every corpus tile beats the previous one for every query: candidate lists overflow and
     the kernel replays tiles in sub-rounds with compaction -- results must still be exact."""
-    d, n, nq, k = 64, 6000, 300, 10
+    _adversarial(10)
+
+
+def test_adversarial_increasing_scores_large_k():
+    _adversarial(48)
+
+
+def _adversarial(k):
+    d, n, nq = 64, 6000, 300
     u = ds.l2_normalize(ds.make_gaussian(1, d, 9))[0]
     a = np.linspace(0.05, 1.0, n, dtype=np.float32)
     c = (a[:, None] * u[None, :]).astype(np.float16)

@@ -65,6 +65,15 @@ def test_full_size_brute_force(nq, n):
     np.testing.assert_allclose(sc[sub], rv, rtol=0, atol=1e-5)
     assert ds.gap_aware_id_match(ids[sub], sc[sub], ri, rv, tol=1e-5)[1] == 0
     assert ds.recall_at_k(ids[sub], ri) >= 0.999
+    # prefix consistency across k: the k=32 result (no row-count certificate in the batch kernel,
+    # thresholds from scheduled compactions) must start with the k=10 result
+    s32, i32 = ix.search(q, 32)
+    torch.cuda.synchronize()
+    s32, i32 = s32.cpu().numpy(), i32.cpu().numpy()
+    _properties(s32, i32, n, 32)
+    assert (i32[:, :k] == ids).all() and np.array_equal(s32[:, :k], sc)
+    rv32, ri32 = ds.brute_force_topk(q16[:6], c32, 32, block=131072)
+    assert ds.gap_aware_id_match(i32[sub[:6]], s32[sub[:6]], ri32, rv32, tol=1e-5)[1] == 0
     # one query at a time (online kernel) == the batch kernel
     s1, i1 = ix.search(q[:3], k)
     torch.cuda.synchronize()
