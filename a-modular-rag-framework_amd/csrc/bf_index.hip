@@ -42,6 +42,7 @@
 //   Adversarial inputs (every tile beats the last) take the replay path every tile: slower,
 //   never wrong.
 #include "common.h"
+#include <type_traits>
 
 #include <math.h>
 #include <stdlib.h>
@@ -160,13 +161,15 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 #define MRAG_A_POLICY ""
 #endif
 
-// Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG build (make DIAG=1);
+// Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG=<flags> build (make DIAG=<flags>):
+// the flags are COMPILE-TIME constants, so an ablated build carries no extra branches or registers
+// (run-time flags cost the K loop its register budget and made every ablation read 15-30 % slow).
 // the production kernel carries none of them.
 #ifdef MRAG_DIAG
-#define MRAG_DBG(bit) (p.dbg & (bit))
+#define MRAG_DBG(bit) ((MRAG_DIAG) & (bit))
 #define MRAG_STAMP(i)                                                                     \
   do {                                                                                    \
-    if ((p.dbg & 16) && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {                    \
+    if (((MRAG_DIAG) & 16) && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {               \
       p.stamps[stamp_n * 2] = (i);                                                        \
       p.stamps[stamp_n * 2 + 1] = (long long)__builtin_readcyclecounter();                \
       ++stamp_n;                                                                          \
@@ -367,6 +370,13 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   int stamp_n = 0;
 #endif
   MRAG_STAMP(0);
+#ifdef MRAG_DIAG
+  // diag 256: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, workgroup 0 (MI355X_MICROARCH.md, DVFS item 6)
+  if (((MRAG_DIAG) & 256) && p.stamps && blockIdx.x == 0 && tid == 0) {
+    p.stamps[120] = (long long)__builtin_amdgcn_s_memtime();
+    p.stamps[121] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
 
   // ---- block -> (query tile, corpus tile range) ----------------------------------------------
   int wg, q_row0, nq_local, tile_lo, tile_hi, rows_end;
@@ -490,32 +500,77 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   __syncthreads();
   MRAG_STAMP(1);
 
-  for (int ti = 0; ti < n_tiles; ++ti) {
-   for (int kk = 0; kk < ksteps; ++kk) {
+  // One K step: prefetch the next stage, then this stage's fragment reads + 64 MFMAs per wave.
+  // PENDING: the previous K step of this corpus tile left its k-half-1 fragments in f1a/f1b;
+  // !PENDING = first K step of a corpus tile: its MFMAs start from a zero C operand (an inline
+  // constant), so the accumulators are never cleared by separate instructions.
+  frag f1a[8], f1b[NF];
+  auto kstep = [&](auto pending_tag) {
+    constexpr bool PENDING = decltype(pending_tag)::value;
     if (pf_left > 0 && !MRAG_DBG(4)) {   // diag 4: ablate the loads
       stage(a_tile + pf_kk * (BK * 2), q_ptr + pf_kk * (BK * 2), buf ^ 1);
       --pf_left;
       if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
     }
-
     const char* sb = smem + buf * STAGE_BYTES;
+    buf ^= 1;
+    if (MRAG_DBG(8)) return;   // diag 8: ablate LDS reads + MFMA
+    {
+      // Software-pipelined fragment reads, two register sets.  The 12 reads of k half 0 are issued
+      // first; the 32 MFMAs of k half 1 of the PREVIOUS step (operands already in registers) run
+      // while they land; then the 32 MFMAs of half 0 run with the 12 reads of half 1 interleaved.
+      // The MFMA pipe never waits on a read it has just issued (hipcc's own order re-reads two
+      // fragments per 4-8 MFMAs and waits on each: 65 % MFMA duty at 2.15 GHz in the reads + MFMA
+      // ablation).  Accumulation order is unchanged: half 0, half 1 of every K step in sequence.
+      const int ph1 = ph0 ^ 64;
+      frag f0a[8], f0b[NF];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (MRAG_DBG(8)) break;   // diag 8: ablate LDS reads + MFMA
-      const int ph = ks ? (ph0 ^ 64) : ph0;
-      frag af[8], bfr[NF];
+      for (int nf = 0; nf < NF; ++nf) f0b[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph0);
 #pragma unroll
-      for (int mf = 0; mf < 8; ++mf) af[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph);
+      for (int mf = 0; mf < 8; ++mf) f0a[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PENDING) {
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) bfr[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph);
+        for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) f1b[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph1);
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) f1a[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph1);
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(af[mf], bfr[nf], acc[mf][nf]);
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = Mfma<DT>::run(f0a[mf], f0b[nf], PENDING ? acc[mf][nf] : (f32x4){0.f, 0.f, 0.f, 0.f});
+      // pin the interleave: 4 MFMAs, then 2 / 1 LDS reads, eight times (12 reads under 32 MFMAs)
+#define MRAG_SGB(n_rd) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, n_rd, 0);
+      MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1)
+#undef MRAG_SGB
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this stage buffer has returned before the next barrier lets it be restaged
     }
-    buf ^= 1;
+  };
+  auto kstep_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage prefetched during this step has landed
+    __syncthreads();
+  };
 
-    if (kk == ksteps - 1 && MRAG_DBG(1)) {
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    kstep(std::false_type{});
+    for (int kk = 1; kk < ksteps; ++kk) {
+      kstep_sync();
+      kstep(std::true_type{});
+    }
+    if (!MRAG_DBG(8)) {   // drain: k half 1 of the last K step
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+    }
+    if (MRAG_DBG(1)) {
       // ablation: no top-k filter; keep the accumulators observable, then clear them
       float x = 0.f;
 #pragma unroll
@@ -523,10 +578,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
           x += acc[mf][nf][0] + acc[mf][nf][1] + acc[mf][nf][2] + acc[mf][nf][3];
-          acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       if (x == 123456.789f) kcnt[0] = 1;
-    } else if (kk == ksteps - 1) {
+    } else {
       // =========================== fused top-k epilogue ===================================
       const int tile = tile_lo + ti;   // ti = tile index inside the split
       // lane-derived values are recomputed from an opaque copy so that nothing the epilogue
@@ -698,6 +752,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
           }
         }
         MRAG_STAMP(12 + (ti == 0 ? 0 : 100));
+        // This barrier also publishes the stage prefetched during the last K step (every wave waits
+        // for its own LDS-DMA loads first), so the common path needs no second barrier per tile.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         MRAG_STAMP(13 + (ti == 0 ? 0 : 100));
         if (attempt == 0) {
@@ -733,7 +790,11 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
           thr[nf] = fmaxf(thr[nf], th);
         }
       }
+      // With one K step per tile nothing else separates this tile's flag / certificate words from the
+      // next tile's epilogue; the forced compaction below uses the scratch buffer after the barrier.
+      bool resync = ksteps == 1;
       if (!certify && ((ti + 1) & ti) == 0 && ti + 1 < n_tiles) {
+        resync = true;
         // k > K_CERT has no row-count certificate: thresholds come from compaction alone (tau_c =
         // the k-th best listed so far).  Compact every query after tiles 0, 1, 3, 7, 15, ... of the
         // split: each interval then lists ~k entries per query (the rows seen double, the rate of
@@ -750,18 +811,14 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
         }
       }
       MRAG_STAMP(14 + (ti == 0 ? 0 : 100));
-#pragma unroll
-      for (int mf = 0; mf < 8; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (resync) __syncthreads();
+      // (the accumulators are not cleared: the first K step of the next tile starts from a zero C operand)
       // The K loop's lane constants may have been spilled around the epilogue.  Touch them HERE so
       // that the compiler's reload (and its s_waitcnt vmcnt, which would also drain the LDS-DMA
       // prefetch it cannot see) sits at the end of the epilogue, not inside the next K step.
       asm volatile("" :: "v"(a_rd), "v"(b_rd), "v"(ph0), "v"(voff_e), "v"(voff_o));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage prefetched during this step has landed
-    __syncthreads();
-   }
+    if (MRAG_DBG(1)) kstep_sync();
   }
 
   __syncthreads();
@@ -785,6 +842,12 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   }
   __syncthreads();
   MRAG_STAMP(99);
+#ifdef MRAG_DIAG
+  if (((MRAG_DIAG) & 256) && p.stamps && blockIdx.x == 0 && tid == 0) {
+    p.stamps[122] = (long long)__builtin_amdgcn_s_memtime();
+    p.stamps[123] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
   if (tid < TQ) p.counts[(size_t)wg * TQ + tid] = kcnt[tid];
 }
 
@@ -1178,17 +1241,16 @@ constexpr int MAX_QTILES_PER_LAUNCH = 64;
 // the 4-wave / one-wave-per-SIMD form (NF = 8, 256 accumulator registers per lane) is correct but
 // hipcc's allocation of the 256-AGPR tile spills into the K loop (98 ms vs 13.6 ms, round-1 measurement).
 static int launch_k2(int dtype, size_t grid, hipStream_t stream, const BfParams& p) {
+  typedef void (*K2Fn)(BfParams);
+  static const K2Fn fns[2] = {bf_gemm_topk_kernel<MRAG_F16, 4>, bf_gemm_topk_kernel<MRAG_BF16, 4>};
   static bool attr_done[2] = {false, false};
   const int di = dtype == MRAG_F16 ? 0 : 1;
   if (!attr_done[di]) {
-    const void* fn = di == 0 ? (const void*)bf_gemm_topk_kernel<MRAG_F16, 4> : (const void*)bf_gemm_topk_kernel<MRAG_BF16, 4>;
-    MRAG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    MRAG_HIP(hipFuncSetAttribute((const void*)fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr_done[di] = true;
   }
   if (!grid) return MRAG_OK;
-  const dim3 g((unsigned)grid), b(NTHR);
-  if (di == 0) hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_F16, 4>), g, b, LDS_TOTAL, stream, p);
-  else hipLaunchKernelGGL((bf_gemm_topk_kernel<MRAG_BF16, 4>), g, b, LDS_TOTAL, stream, p);
+  hipLaunchKernelGGL(fns[di], dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
@@ -1206,10 +1268,8 @@ int bf_launch(const BfLaunch& a) {
   p.stamps = nullptr;
 #ifdef MRAG_DIAG
   {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("MRAG_DEBUG_FLAGS"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-    if (p.dbg & 16) {
+    p.dbg = MRAG_DIAG;
+    if (p.dbg & (16 | 256)) {
       if (!g_stamps) MRAG_HIP(hipMalloc((void**)&g_stamps, 128 * 8));
       MRAG_HIP(hipMemsetAsync(g_stamps, 0, 128 * 8, stream));
       p.stamps = g_stamps;
@@ -1299,6 +1359,13 @@ int bf_launch(const BfLaunch& a) {
     hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)nq), dim3(64), 0, stream, mp);
     MRAG_HIP(hipGetLastError());
 #ifdef MRAG_DIAG
+    if (g_stamps && (p.dbg & 256)) {
+      long long hs[128];
+      MRAG_HIP(hipStreamSynchronize(stream));
+      MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+      const double dc = (double)(hs[122] - hs[120]), dr = (double)(hs[123] - hs[121]);
+      if (dr > 0) fprintf(stderr, "[mrag clock] workgroup 0: %.0f cycles in %.1f us -> %.3f GHz\n", dc, dr / 100.0, dc / dr * 0.1);
+    }
     if (g_stamps && (p.dbg & 16)) {
       long long hs[128];
       MRAG_HIP(hipStreamSynchronize(stream));

@@ -1,10 +1,14 @@
 #!/bin/bash
-# K2 ablations on the GPU box (diagnostic build, timing only; results are wrong by design):
-#   1 no epilogue | 4 no loads | 8 no LDS reads / MFMA | 32 no list pushes | 128 every corpus tile = the first (L2-resident)
+# K2 ablations on the GPU box (diagnostic builds, timing only; results are wrong by design).
+# Flags are compile-time (-DMRAG_DIAG=<flags>), one rebuild of bf_index.hip per flag set:
+#   1 no epilogue | 4 no loads | 8 no LDS reads / MFMA | 32 no list pushes | 256 in-kernel clock
 set -e
 cd "$(dirname "$0")/.."
-make -C a-modular-rag-framework_amd/csrc DIAG=1 -B > gpurun_out/ablate_make.log 2>&1
-for f in ${FLAGS:-0 1 5 9 137 129 128}; do
-  echo "flags=$f"
-  MRAG_DEBUG_FLAGS=$f python tools/quick_perf.py ${SHAPE:-10000x1000000x768}
+for f in ${FLAGS:-1 5 9}; do
+  touch a-modular-rag-framework_amd/csrc/bf_index.hip
+  make -C a-modular-rag-framework_amd/csrc DIAG=$f > gpurun_out/ablate_make.log 2>&1
+  for pp in ${PIPES:-0 1}; do
+    echo "flags=$f pipe=$pp"
+    MRAG_PIPE=$pp ITERS=${ITERS:-5} python tools/quick_perf.py ${SHAPE:-10000x1000000x768} 2>&1 | grep -v amdgpu.ids | tail -${TAIL:-1}
+  done
 done

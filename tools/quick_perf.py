@@ -9,7 +9,7 @@ import torch
 from mrag_amd.index import DenseIndex
 
 
-def run(nq, n, d, k=10, iters=5):
+def run(nq, n, d, k=10, iters=int(__import__('os').environ.get('ITERS', '5'))):
     g = torch.Generator(device="cuda").manual_seed(1234)
     ix = DenseIndex(d)
     step = 262144
