@@ -69,7 +69,10 @@ constexpr int SEG = 64;                   // private list segment per (query, la
 constexpr int KEPT = 64;                  // compacted entries per query (= largest k)
 constexpr int QCAP = KEPT + NGRP * SEG;   // 576 list entries per (workgroup, query)
 constexpr int KMAX = KEPT;
-constexpr int DENSE_TILES = 8;             // tiles of a split filtered by the mask + LDS path (see the epilogue)
+#ifndef MRAG_DENSE_TILES
+#define MRAG_DENSE_TILES 8
+#endif
+constexpr int DENSE_TILES = MRAG_DENSE_TILES;             // tiles of a split filtered by the mask + LDS path (see the epilogue)
 constexpr int K_CERT = 16;                // k served by the 16-row threshold certificate
 
 constexpr int OFF_TAU = GEMM_LDS;               // float[256]      k-th best after a compaction
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   #pragma unroll
             for (int mf = 0; mf < 8; ++mf) tm = fmaxf(tm, fmaxf(fmaxf(acc[mf][nf][0], acc[mf][nf][1]), fmaxf(acc[mf][nf][2], acc[mf][nf][3])));
             tmax[nf] = tm;
-            if (!__any(tm > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
+            if (!__any(tm > thr[nf]) || MRAG_DBG(32 | 512)) continue;   // dbg 32: ablate list pushes (512: of the dense path only)
             uint32_t pm = 0u;
   #pragma unroll
             for (int mf = 7; mf >= 0; --mf)
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
               const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
               tm = fmaxf(tm, m4);
               if (attempt && (mf >> 1) != round) continue;      // replay: 2 accumulators (<= 8 pushes/segment) per round
-              if (!__any(m4 > thr[nf]) || MRAG_DBG(32)) continue;   // dbg 32: ablate list pushes
+              if (!__any(m4 > thr[nf]) || MRAG_DBG(32 | 1024)) continue;   // dbg 32: ablate list pushes (1024: of the sparse path only)
   #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 if (a[j] > thr[nf]) {
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   // ---- end of the split: every query's list is cut to its k best (sorted) so that K4 only has to
   // merge S x k entries.  Entries below the final certified threshold are dropped before ranking
   // (typically ~25 of ~170 survive), which is what keeps this tail at ~1 % of the workgroup's time.
-  if (n_tiles > 0) {
+  if (n_tiles > 0 && !MRAG_DBG(2048)) {   // dbg 2048: ablate the end-of-split compaction
     const uint32_t* stat_last = stat + ((n_tiles - 1) & 1) * TQ;
     uint64_t* scratch = (uint64_t*)(smem + w * 8192);
     for (int qq = 0; qq < QPW; qq += 4) {

@@ -159,12 +159,13 @@ def main():
                                   "kernel_ms": on_ms, "achieved": on_bytes / (on_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": on_bytes / (on_ms * 1e-3) / 1e9 / 8000.0, "bytes_per_launch": on_bytes}
         # HBM-side traffic of K2 comes from separate rocprofv3 --pmc passes of this same command
-        # (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/r01_pmc_traffic.json)
-        pmc = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if world == 1 and (n, nq, d) == (N_CORPUS, N_QUERIES, DIM) and pmc.exists():
+        # (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/r*_pmc_traffic.json, tools/profile_round.sh)
+        pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
+        if world == 1 and (n, nq, d) == (N_CORPUS, N_QUERIES, DIM) and pmcs:
             try:
+                pmc = pmcs[-1]   # the latest round's counters (tools/profile_round.sh)
                 out["roofline"]["traffic"] = json.loads(pmc.read_text())["kernels"]["bf_gemm_topk"]["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "bytes/launch, L2<->fabric requests (Infinity-Cache hits included); profiles/r01_pmc_traffic.json"
+                out["roofline"]["traffic_note"] = f"bytes/launch, L2<->fabric requests (Infinity-Cache hits included); profiles/{pmc.name}"
             except Exception:
                 pass
         if world == 1 and not args.no_cpu:
