@@ -172,7 +172,7 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 #define MRAG_DBG(bit) ((MRAG_DIAG) & (bit))
 #define MRAG_STAMP(i)                                                                     \
   do {                                                                                    \
-    if (((MRAG_DIAG) & 16) && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {               \
+    if (((MRAG_DIAG) & 16) && stamp_on && blockIdx.x == 0 && tid == 0 && stamp_n < 64) {   \
       p.stamps[stamp_n * 2] = (i);                                                        \
       p.stamps[stamp_n * 2 + 1] = (long long)__builtin_readcyclecounter();                \
       ++stamp_n;                                                                          \
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   const int wm = w / WN, wn = w % WN;
 #ifdef MRAG_DIAG
   int stamp_n = 0;
+  bool stamp_on = true;   // narrowed to tiles 60..65 of the split inside the tile loop (the sparse regime)
 #endif
   MRAG_STAMP(0);
 #ifdef MRAG_DIAG
@@ -562,6 +563,10 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   };
 
   for (int ti = 0; ti < n_tiles; ++ti) {
+#ifdef MRAG_DIAG
+    stamp_on = ti >= 60 && ti < 66;
+    MRAG_STAMP(2);
+#endif
     kstep(std::false_type{});
     for (int kk = 1; kk < ksteps; ++kk) {
       kstep_sync();
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
     }
+    MRAG_STAMP(3);
     if (MRAG_DBG(1)) {
       // ablation: no top-k filter; keep the accumulators observable, then clear them
       float x = 0.f;
@@ -594,6 +600,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
       const int q0 = wn * (16 * NF) + (elane & 15);              // + nf*16
       const int grp = wm * 4 + (elane >> 4);                     // this lane's segment of each of its queries
       const bool certify = p.k <= K_CERT;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage prefetched during the last K step has landed (issued a K step ago: no stall)
       MRAG_STAMP(10 + (ti == 0 ? 0 : 100));
       if ((tile + 1) * TM > rows_end) {
 #pragma unroll
@@ -709,13 +716,22 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
             uint2* lst = wg_list + (size_t)q * QCAP + KEPT + grp * SEG;
             float tm = -INFINITY;
             int c = cseg[nf];
+            // all eight group tests first (8 v_cmp into 8 SGPR pairs, back to back), then scalar-only
+            // branches on the saved masks: a v_cmp -> s_cbranch_vcc pair per group serialises the vector
+            // and scalar pipes (~33 cycles per test measured)
+            unsigned long long hit[8];
   #pragma unroll
             for (int mf = 0; mf < 8; ++mf) {
               const f32x4 a = acc[mf][nf];
               const float m4 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
               tm = fmaxf(tm, m4);
+              hit[mf] = __ballot(m4 > thr[nf]);
+            }
+  #pragma unroll
+            for (int mf = 0; mf < 8; ++mf) {
+              const f32x4 a = acc[mf][nf];
               if (attempt && (mf >> 1) != round) continue;      // replay: 2 accumulators (<= 8 pushes/segment) per round
-              if (!__any(m4 > thr[nf]) || MRAG_DBG(32 | 1024)) continue;   // dbg 32: ablate list pushes (1024: of the sparse path only)
+              if (hit[mf] == 0ull || MRAG_DBG(32 | 1024)) continue;   // dbg 32: ablate list pushes (1024: of the sparse path only)
   #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 if (a[j] > thr[nf]) {
@@ -755,10 +771,15 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
           }
         }
         MRAG_STAMP(12 + (ti == 0 ? 0 : 100));
-        // This barrier also publishes the stage prefetched during the last K step (every wave waits
-        // for its own LDS-DMA loads first), so the common path needs no second barrier per tile.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // This barrier also publishes the stage prefetched during the last K step (every wave waited
+        // for its own LDS-DMA loads at the top of the epilogue), so the common path needs no second
+        // barrier per tile.  It is a RAW barrier behind an LDS-only wait: the list stores of this tile
+        // stay in flight across it (nobody reads the lists before one of the full __syncthreads() of the
+        // replay / compaction / end-of-split paths) -- __syncthreads() here made every wave sit out the
+        // completion latency of its last 8-byte store on every tile.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         MRAG_STAMP(13 + (ti == 0 ? 0 : 100));
         if (attempt == 0) {
           if (!flags[0]) {
@@ -793,6 +814,42 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
           thr[nf] = fmaxf(thr[nf], th);
         }
       }
+      // Sharper certificate, refreshed after tiles 0..7, 15, 31, 63, ... of the split: the min over the
+      // 8 lanes of their 2nd largest maxima (stat) sits near the 38th best score so far; the k-th
+      // LARGEST of the 16 certified maxima (8 lanes x top 2, all distinct earlier rows) is just as valid
+      // -- k rows reach it -- and close to the k-th best.  One thread per query sorts the 16 values
+      // (bitonic network in registers) and raises tau_c.  Simulated list pushes per (query, split) at
+      // k = 10: 231 -> 112 (an exact k-th-best threshold: 88).
+      if (certify && p.k < K_CERT && (ti < 8 || ((ti + 1) & ti) == 0) && ti + 1 < n_tiles) {
+        if (tid < TQ) {
+          const int cq = tid & 15, cnf = (tid >> 4) & 3, cwn = tid >> 6;
+          float v[16];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {   // owner lanes of query `tid`: wave row o>>2, lane group o&3
+            const int owner = ((o >> 2) * WN + cwn) * 64 + (o & 3) * 16 + cq;
+            v[2 * o] = __uint_as_float(rm[(cnf * 2 + 0) * NT + owner]);
+            v[2 * o + 1] = __uint_as_float(rm[(cnf * 2 + 1) * NT + owner]);
+          }
+#pragma unroll
+          for (int kk2 = 2; kk2 <= 16; kk2 <<= 1)
+#pragma unroll
+            for (int j = kk2 >> 1; j > 0; j >>= 1)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                  const float lo = fminf(v[i], v[l]), hi = fmaxf(v[i], v[l]);
+                  const bool desc = (i & kk2) == 0;          // descending overall: v[0] largest
+                  v[i] = desc ? hi : lo;
+                  v[l] = desc ? lo : hi;
+                }
+              }
+          float sel = v[15];
+#pragma unroll
+          for (int i = 14; i >= 0; --i) sel = (i == p.k - 1) ? v[i] : sel;
+          tau_c[tid] = fmaxf(tau_c[tid], sel);
+        }
+      }
       // With one K step per tile nothing else separates this tile's flag / certificate words from the
       // next tile's epilogue; the forced compaction below uses the scratch buffer after the barrier.
       bool resync = ksteps == 1;
@@ -825,6 +882,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   }
 
   __syncthreads();
+#ifdef MRAG_DIAG
+  stamp_on = true;
+#endif
   MRAG_STAMP(98);
   // ---- end of the split: every query's list is cut to its k best (sorted) so that K4 only has to
   // merge S x k entries.  Entries below the final certified threshold are dropped before ranking
