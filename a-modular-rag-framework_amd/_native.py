@@ -60,6 +60,7 @@ SIGNATURES = {
     "mrag_index_search": [_h, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mrag_index_last_timing": [_h, _fp, _fp],
     "mrag_topk_merge": [_vp, _vp, _i, _i64, _i, _vp, _vp, _i],
+    "mrag_topk_merge_device": [_i, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp],
     "mrag_ivf_create": [_i, _i, _i, _i, _i, C.POINTER(_h)],
     "mrag_ivf_destroy": [_h],
     "mrag_ivf_train": [_h, _vp, _i64, _i, _i, _i, _i, C.c_uint64, _vp],

@@ -171,6 +171,28 @@ def topk_merge(scores: np.ndarray, ids: np.ndarray, nthreads: int = 0) -> Tuple[
     return os_, oi
 
 
+def topk_merge_device(scores, ids, out_scores=None, out_ids=None):
+    """The same merge on the GPU (``mrag_topk_merge_device``) for gathered partial top-k that
+    already sits in HBM: ``scores`` float32 / ``ids`` int64 CUDA tensors [nparts, nq, k] (each
+    part sorted, empties last) -> CUDA tensors [nq, k].  Asynchronous on the current stream."""
+    import torch
+    if not (torch.is_tensor(scores) and scores.is_cuda and torch.is_tensor(ids) and ids.is_cuda):
+        raise ValueError("topk_merge_device expects CUDA tensors (use topk_merge for host arrays)")
+    if scores.dim() != 3 or scores.shape != ids.shape or scores.dtype != torch.float32 or ids.dtype != torch.int64:
+        raise ValueError("expected matching [nparts, nq, k] float32 / int64 tensors")
+    scores, ids = scores.contiguous(), ids.contiguous()
+    nparts, nq, k = scores.shape
+    dev = scores.device
+    if out_scores is None:
+        out_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    if out_ids is None:
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    N.check(N.load().mrag_topk_merge_device(dev.index or 0, scores.data_ptr(), ids.data_ptr(), nparts, nq, k,
+                                            out_scores.data_ptr(), out_ids.data_ptr(), stream))
+    return out_scores, out_ids
+
+
 class IVFFlatIndex:
     """IVF-flat index on one GPU (BASELINE.json config 5): nlist spherical-k-means lists, every
     search probes the ``nprobe`` best lists and scans them exactly.  Same id / tie-break

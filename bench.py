@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec of brute-force cosine top-10 over the 1M x 768 fp16 corpus
 (BASELINE.json metric; workload = config C4: a 10 000-query batch, corpus row-sharded over the
-N GPUs of one node, one RCCL all-gather of the per-shard partial top-k + host merge).
+N GPUs of one node, one RCCL all-gather of the per-shard partial top-k + merge on the device).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -144,7 +144,7 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "C4: 10k-query batch x 1M x 768 fp16 corpus, k=10, corpus row-sharded across GPUs, "
-                                   "all-gather partial top-k + host merge",
+                                   "all-gather partial top-k + device merge",
                        "n_queries": nq, "n_corpus": n, "dim": d, "k": k,
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",

@@ -102,6 +102,13 @@ int mrag_index_last_timing(mrag_handle h, float* out_gemm_ms, float* out_total_m
 int mrag_topk_merge(const float* scores, const int64_t* ids, int nparts, int64_t nq, int k,
                     float* out_scores, int64_t* out_ids, int nthreads);
 
+/* the same merge for buffers that already sit in HBM (the RCCL all-gather output): every pointer is a
+ * device pointer on `device`, asynchronous on `stream`.  Each part must be sorted (score desc, id asc)
+ * with its empty slots last, as mrag_index_search produces them.  Serves nparts <= 64 and
+ * nparts * k <= 2048; larger requests return MRAG_ERR_UNSUPPORTED (use the host merge). */
+int mrag_topk_merge_device(int device, const float* scores, const int64_t* ids, int nparts, int64_t nq, int k,
+                           float* out_scores, int64_t* out_ids, void* stream);
+
 /* ---- IVF-flat (BASELINE.json config 5; no counterpart in the reference) ----------- */
 int mrag_ivf_create(int dim, int nlist, int metric, int storage_dtype, int device, mrag_handle* out);
 int mrag_ivf_destroy(mrag_handle h);

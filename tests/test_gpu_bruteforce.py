@@ -280,3 +280,39 @@ def test_online_regime_adversarial_and_ties():
         s2, i2 = ix2.search(qi, k, normalize=False)
         rv2, ri2 = ds.brute_force_topk(qi, ci, k)
         assert (i2 == ri2).all() and (s2 == rv2.astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("nparts,nq,k,pool", [(8, 300, 10, 200), (2, 17, 1, 5), (3, 64, 64, 100), (64, 9, 32, 3000),
+                                              (5, 40, 7, 20)])
+def test_device_merge_matches_host_merge(nparts, nq, k, pool):
+    """8e on the device: mrag_topk_merge_device == mrag_topk_merge (score desc, id asc, empties last),
+    ties and short parts included."""
+    import torch
+    from mrag_amd.index import topk_merge, topk_merge_device
+    rng = np.random.default_rng(nparts * 1000 + k)
+    sc = np.full((nparts, nq, k), -np.inf, dtype=np.float32)
+    ids = np.full((nparts, nq, k), -1, dtype=np.int64)
+    for q in range(nq):
+        gid = rng.permutation(pool).astype(np.int64) + 5_000_000_000 * (q % 2)     # ids beyond 2^32 too
+        val = rng.integers(0, 12, size=pool).astype(np.float32) / 4                 # many exact ties
+        owner = rng.integers(0, nparts, size=pool)
+        for p_ in range(nparts):
+            m = owner == p_
+            order = np.lexsort((gid[m], -val[m]))[:k]
+            sc[p_, q, :len(order)] = val[m][order]
+            ids[p_, q, :len(order)] = gid[m][order]
+    hs, hi = topk_merge(sc, ids)
+    ds_, di = topk_merge_device(torch.from_numpy(sc).cuda(), torch.from_numpy(ids).cuda())
+    torch.cuda.synchronize()
+    assert (di.cpu().numpy() == hi).all()
+    assert np.array_equal(ds_.cpu().numpy(), hs)
+
+
+def test_device_merge_limits_are_loud():
+    import torch
+    from mrag_amd import _native as N
+    from mrag_amd.index import topk_merge_device
+    with pytest.raises(N.MragError):
+        topk_merge_device(torch.zeros((65, 2, 4), device="cuda"), torch.zeros((65, 2, 4), dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        topk_merge_device(torch.zeros((2, 2, 4)), torch.zeros((2, 2, 4), dtype=torch.int64))

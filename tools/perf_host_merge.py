@@ -24,3 +24,12 @@ for nparts in (2, 4, 8):
         for _ in range(10):
             hs.copy_(gs, non_blocking=True); hi.copy_(gi, non_blocking=True); torch.cuda.synchronize()
         print(f"  pinned D2H of {gs.numel()*12/1e6:.1f} MB: {(time.perf_counter()-t)/10*1e3:.3f} ms", flush=True)
+        # the device leg that replaces both: mrag_topk_merge_device + D2H of the merged [nq, k] only
+        from mrag_amd.index import topk_merge_device
+        ms = torch.empty((nq, k), dtype=torch.float32, device="cuda"); mi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        hms = torch.empty((nq, k), dtype=torch.float32).pin_memory(); hmi = torch.empty((nq, k), dtype=torch.int64).pin_memory()
+        topk_merge_device(gs, gi, ms, mi); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(10):
+            topk_merge_device(gs, gi, ms, mi); hms.copy_(ms, non_blocking=True); hmi.copy_(mi, non_blocking=True); torch.cuda.synchronize()
+        print(f"  device merge + D2H of the merged {nq*k*12/1e6:.1f} MB: {(time.perf_counter()-t)/10*1e3:.3f} ms", flush=True)
