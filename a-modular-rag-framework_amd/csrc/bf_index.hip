@@ -204,9 +204,11 @@ __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, in
   int* scnt = (int*)(smem + OFF_SCNT);
   uint32_t* hist = (uint32_t*)(scratch + QCAP);
   uint64_t* sel = scratch + QCAP + 128;
-  int shift = 64;              // keys with (key >> shift) >= prefix are selected once the loop ends
+  int shift = 0;               // keys with (key >> shift) >= prefix are selected once the loop ends
   uint64_t prefix = 0ull;
-  if (total > k) {
+  // <= 64 staged keys (the usual case at the end of a split, after pruning): one key per lane, ranked
+  // directly below -- no selection pass at all
+  if (total > 64) {
     int need = k;
     for (shift = 56; shift >= 0; shift -= 8) {
       *(uint4*)&hist[lane * 4] = make_uint4(0u, 0u, 0u, 0u);
@@ -244,26 +246,31 @@ __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, in
     }
     if (shift < 0) shift = 0;
   }
-  // gather the selected keys (exactly min(total, k) of them)
-  int nsel = 0;
-  for (int base = 0; base < total; base += 64) {
-    const int i = base + lane;
-    const uint64_t key = i < total ? scratch[i] : 0ull;
-    const bool pick = i < total && (shift >= 64 || (key >> shift) >= prefix);
-    const unsigned long long bal = __ballot(pick);
-    if (pick) sel[nsel + __popcll(bal & ((1ull << lane) - 1ull))] = key;
-    nsel += __popcll(bal);
+  int nsel = total;
+  const uint64_t* cand = scratch;
+  if (total > 64) {
+    // gather the selected keys (exactly k of them)
+    nsel = 0;
+    for (int base = 0; base < total; base += 64) {
+      const int i = base + lane;
+      const uint64_t key = i < total ? scratch[i] : 0ull;
+      const bool pick = i < total && (key >> shift) >= prefix;
+      const unsigned long long bal = __ballot(pick);
+      if (pick) sel[nsel + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+      nsel += __popcll(bal);
+    }
+    cand = sel;
   }
   __builtin_amdgcn_wave_barrier();
-  const uint64_t my = lane < nsel ? sel[lane] : 0ull;
+  const uint64_t my = lane < nsel ? cand[lane] : 0ull;
   int rank = 0;
-  for (int j = 0; j < nsel; ++j) rank += (sel[j] > my) ? 1 : 0;
-  if (lane < nsel) {
+  for (int j = 0; j < nsel; ++j) rank += (cand[j] > my) ? 1 : 0;
+  if (lane < nsel && rank < k) {
     const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
     lst[rank] = make_uint2(sb, 0xFFFFFFFFu - (uint32_t)my);
     if (rank == k - 1) tau_c[q] = __uint_as_float(sb);
   }
-  if (lane == 0) kcnt[q] = nsel;
+  if (lane == 0) kcnt[q] = min(nsel, k);
   if (lane < NGRP) scnt[q * NGRP + lane] = 0;
 }
 
