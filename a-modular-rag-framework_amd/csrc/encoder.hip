@@ -19,6 +19,9 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
 #include <map>
 #include <string>
 
@@ -258,6 +261,180 @@ __global__ __launch_bounds__(GTHR) void enc_gemm_kernel(const uint16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------ 256 x 256 persistent GEMM (the K2 main loop)
+// Used when N_pad % 256 == 0 and M_pad % 256 == 0.  Same structure as the similarity kernel of
+// bf_index.hip: 8 waves (2 x 4), 256 x 256 x 64 stages through LDS-DMA issued from inline asm (scalar
+// base + 32-bit voffset, XOR swizzle on the source address), two fragment register sets so that the
+// MFMA pipe never waits on a read it has just issued, zero C operand on the first K step of a tile,
+// one barrier per K step.  Workgroups are persistent: each walks tiles lin = first, first + stride, ...
+// and prefetches the first stage of its next tile during the last K step of the current one.
+// The WEIGHT rows are the MFMA A operand and the token rows the B operand, so a lane's four accumulator
+// values are four consecutive OUTPUT columns of one token: bias / GELU / residual apply to 8-byte
+// groups and the stores are 8 bytes per lane (the 128 x 128 kernel above stores 2 bytes at a time).
+constexpr int G2_T = 256, G2_THR = 512;
+constexpr int G2_A_BYTES = G2_T * GK * 2;            // 32 KiB: weight rows of a stage
+constexpr int G2_STAGE = 2 * G2_A_BYTES;             // 64 KiB
+constexpr int G2_LDS = 2 * G2_STAGE;                 // 128 KiB
+
+template <int DT, int EPI>
+__global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                                const float* __restrict__ bias, const uint16_t* __restrict__ R,
+                                                                uint16_t* __restrict__ C, int N, int K, int tiles_m, int tiles_n) {
+  typedef typename EMfma<DT>::frag frag;
+  typedef typename EMfma<DT>::elem elem;
+  typedef elem e4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char sm2[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;     // wave tile: 128 weight rows (output columns) x 64 tokens
+  const int ksteps = K / GK;
+  const int n_tiles = tiles_m * tiles_n;
+  // XCD-aware start: the workgroups of one XCD (blockIdx % 8) take consecutive tiles, which walk N first
+  // and share the token panel in that XCD's L2
+  const int nwg = gridDim.x;
+  const int first = (nwg % 8 == 0) ? (int)(blockIdx.x & 7) * (nwg / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const uint32_t row_b = (uint32_t)K * 2u;
+  const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
+  const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);
+  const uint32_t chunk_b = 8u * row_b;
+  const size_t wave_off = (size_t)(4 * w) * chunk_b;     // wave w fills 1-KiB chunks 4w..4w+3 of each operand
+  auto tile_ptrs = [&](int lin, const char*& a, const char*& b) {
+    const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+    a = (const char*)(W + (size_t)tn * G2_T * K) + wave_off;
+    b = (const char*)(X + (size_t)tm * G2_T * K) + wave_off;
+  };
+  auto stage = [&](const char* a, const char* b, int buf) {
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const char* base = op ? b : a;
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        const uint32_t la = (uint32_t)(buf * G2_STAGE + op * G2_A_BYTES + (4 * w + i) * 1024);
+        const char* c0 = base + (size_t)i * chunk_b;
+        const char* c1 = c0 + chunk_b;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
+            : "memory", "scc");
+      }
+    }
+  };
+  const int frow = lane & 15, fsw = frow >> 1;
+  const int a_rd = (wm * 128 + frow) * 128;
+  const int b_rd = G2_A_BYTES + (wn * 64 + frow) * 128;
+  const int ph0 = ((lane >> 4) ^ fsw) * 16;
+  f32x4 acc[8][4];
+  frag f1a[8], f1b[4];
+
+  // prefetch cursor over the flattened (tile, k step) sequence of this workgroup
+  int pf_lin = first, pf_kk = 0;
+  const char *pf_a = nullptr, *pf_b = nullptr;
+  if (pf_lin < n_tiles) tile_ptrs(pf_lin, pf_a, pf_b);
+  int buf = 0;
+  auto prefetch = [&](int into) {
+    if (pf_lin >= n_tiles) return;
+    stage(pf_a + pf_kk * (GK * 2), pf_b + pf_kk * (GK * 2), into);
+    if (++pf_kk == ksteps) {
+      pf_kk = 0;
+      pf_lin += nwg;
+      if (pf_lin < n_tiles) tile_ptrs(pf_lin, pf_a, pf_b);
+    }
+  };
+  prefetch(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto kstep = [&](auto pending_tag) {
+    constexpr bool PENDING = decltype(pending_tag)::value;
+    prefetch(buf ^ 1);
+    const char* sb = sm2 + buf * G2_STAGE;
+    buf ^= 1;
+    const int ph1 = ph0 ^ 64;
+    frag f0a[8], f0b[4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) f0b[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph0);
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) f0a[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PENDING) {
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = EMfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) f1b[nf] = *(const frag*)(sb + b_rd + nf * 2048 + ph1);
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) f1a[mf] = *(const frag*)(sb + a_rd + mf * 2048 + ph1);
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        acc[mf][nf] = EMfma<DT>::run(f0a[mf], f0b[nf], PENDING ? acc[mf][nf] : (f32x4){0.f, 0.f, 0.f, 0.f});
+#define MRAG_SGB(n_rd) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, n_rd, 0);
+    MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1) MRAG_SGB(2) MRAG_SGB(1)
+#undef MRAG_SGB
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto kstep_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  for (int lin = first; lin < n_tiles; lin += nwg) {
+    kstep(std::false_type{});
+    for (int kk = 1; kk < ksteps; ++kk) {
+      kstep_sync();
+      kstep(std::true_type{});
+    }
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = EMfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+    // the next tile's first stage is in flight: make sure it has landed BEFORE this tile's stores are
+    // issued (vmcnt counts in order), so that the barrier below does not wait for the stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- epilogue: n = tn*256 + wm*128 + mf*16 + (lane>>4)*4 + r, token = tm*256 + wn*64 + nf*16 + (lane&15)
+    const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
+    const int n_b = tn * G2_T + wm * 128 + (lane >> 4) * 4;
+    const int t_b = tm * G2_T + wn * 64 + (lane & 15);
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+      const int n0 = n_b + mf * 16;
+      if (n0 >= N) continue;
+      const float4 bv = *(const float4*)(bias + n0);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const size_t off = (size_t)(t_b + nf * 16) * N + n0;
+        float v[4] = {acc[mf][nf][0] + bv.x, acc[mf][nf][1] + bv.y, acc[mf][nf][2] + bv.z, acc[mf][nf][3] + bv.w};
+        if (EPI == EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+        }
+        if (EPI == EPI_RESID) {
+          const e4 rr = *(const e4*)(R + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+        }
+        e4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (elem)v[r];
+        *(e4*)(C + off) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave's loads of the next first stage have landed (waited above)
+    asm volatile("" ::: "memory");
+  }
+}
+
 // ------------------------------------------------------------------ attention
 // QKV [M_pad][3H] (q | k | v per token), mask [B][S] (1 = token), out [M_pad][H].
 // grid = B * heads * ceil(S/64); 256 threads: wave w owns query rows 16w..16w+15 of the block.
@@ -456,7 +633,7 @@ static int dev_alloc(Encoder* e, void** p, size_t bytes) {
 }
 
 static int alloc_linear(Encoder* e, Linear& l, int N, int K) {
-  l.N = N; l.K = K; l.N_pad = (int)round_up(N, GN);
+  l.N = N; l.K = K; l.N_pad = (int)round_up(N, N >= G2_T ? G2_T : GN);   // 256-row padding lets the 256 x 256 kernel serve it
   MRAG_TRY(dev_alloc(e, (void**)&l.w, (size_t)l.N_pad * K * 2));
   MRAG_TRY(dev_alloc(e, (void**)&l.b, (size_t)l.N_pad * 4));
   return MRAG_OK;
@@ -500,8 +677,28 @@ static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hi
   return MRAG_OK;
 }
 
+// development switch (MRAG_ENC_GEMM128=1): force the 128 x 128 kernel, for A/B timing
+static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM128"); return e && atoi(e) != 0; }();
+
 template <int DT>
 static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M_pad, int epi, hipStream_t stream) {
+  if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && !g_force_gemm128) {
+    typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int);
+    const Fn fn = epi == EPI_BIAS ? (Fn)enc_gemm256_kernel<DT, EPI_BIAS> : epi == EPI_GELU ? (Fn)enc_gemm256_kernel<DT, EPI_GELU>
+                                                                                          : (Fn)enc_gemm256_kernel<DT, EPI_RESID>;
+    static std::map<const void*, bool> attr_done;
+    if (!attr_done[(const void*)fn]) {
+      MRAG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
+      attr_done[(const void*)fn] = true;
+    }
+    const int tm2 = M_pad / G2_T, tn2 = l.N_pad / G2_T;
+    int cus = 256;
+    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+    const int nwg = std::min(tm2 * tn2, cus);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  }
   const int tiles_m = M_pad / GM, tiles_n = l.N_pad / GN;
   const dim3 grid((unsigned)(tiles_m * tiles_n)), block(GTHR);
   if (epi == EPI_BIAS) hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_BIAS>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
@@ -517,7 +714,7 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
   const mrag_encoder_config& c = e->cfg;
   const int H = c.hidden, I = c.intermediate;
   const int64_t M = (int64_t)B * S;
-  const int M_pad = (int)round_up(M, GM);
+  const int M_pad = (int)round_up(M, M >= 2 * G2_T ? G2_T : GM);
   MRAG_TRY(e->x.ensure((size_t)M_pad * H * 2));
   MRAG_TRY(e->y.ensure((size_t)M_pad * H * 2));
   MRAG_TRY(e->qkv.ensure((size_t)M_pad * 3 * H * 2));
