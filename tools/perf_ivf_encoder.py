@@ -56,6 +56,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["ivf", "enc"]
     if "enc" in what:
         encoder("minilm-l6", 4096, 128)
+    if "enc" in what or "enc-bge" in what:
         encoder("bge-base", 2048, 128)
     if "ivf" in what:
         ivf()
