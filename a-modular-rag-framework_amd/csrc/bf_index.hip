@@ -764,18 +764,28 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
         MRAG_STAMP(22);
         if (attempt == 0 && certify && ti != 0) {
           // fold this tile's maxima into the running certificate used from the NEXT tile on
+          // (the four columns as four independent chains: all loads, then all stores, then the shuffles --
+          // written column by column the LDS read -> write -> shuffle -> atomic chain ran serially, 3 % of a tile)
+          float o1[NF], o2[NF], x[NF];
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) {
-            const float o1 = __uint_as_float(rm[(nf * 2 + 0) * NT + tid]);
-            const float o2 = __uint_as_float(rm[(nf * 2 + 1) * NT + tid]);
-            const float n2 = fmaxf(o2, fminf(o1, tmax[nf])), n1 = fmaxf(o1, tmax[nf]);
+            o1[nf] = __uint_as_float(rm[(nf * 2 + 0) * NT + tid]);
+            o2[nf] = __uint_as_float(rm[(nf * 2 + 1) * NT + tid]);
+          }
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const float n2 = fmaxf(o2[nf], fminf(o1[nf], tmax[nf])), n1 = fmaxf(o1[nf], tmax[nf]);
             rm[(nf * 2 + 0) * NT + tid] = __float_as_uint(n1);
             rm[(nf * 2 + 1) * NT + tid] = __float_as_uint(n2);
-            float x = n2;
-            x = fminf(x, __shfl_xor(x, 16));
-            x = fminf(x, __shfl_xor(x, 32));
-            if (elane < 16) lds_min_u32(&stat_cur[q0 + nf * 16], f32_ord(x));
+            x[nf] = n2;
           }
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) x[nf] = fminf(x[nf], __shfl_xor(x[nf], 16));
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) x[nf] = fminf(x[nf], __shfl_xor(x[nf], 32));
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+            if (elane < 16) lds_min_u32(&stat_cur[q0 + nf * 16], f32_ord(x[nf]));
         }
         MRAG_STAMP(12 + (ti == 0 ? 0 : 100));
         // This barrier also publishes the stage prefetched during the last K step (every wave waited
