@@ -33,14 +33,24 @@
 //   (2 waves x 4 lane groups) of their 2nd-largest is a score that >= 16 earlier rows reach
 //   (LDS ds_min, double-buffered per tile); the first tile bootstraps from its own scores and
 //   passes on '>='.  (b) any k: the k-th best of a compacted list.
-//   Lists: each of the 8 lanes that share a query owns a private 32-entry segment of the
+//   (c) k < 16: after tiles 0-7, 15, 31, 63, ... of a split the k-th LARGEST of the 16 certified maxima
+//   replaces their minimum (one thread per query, bitonic network in registers): ~2x fewer listings.
+//   (d) 16 < k <= 64: no row-count certificate; every query is compacted after tiles 0, 1, 3, 7, ...
+//   Lists: each of the 8 lanes that share a query owns a private 64-entry segment of the
 //   query's list (count kept in a register during the push, committed to LDS after the tile's
-//   barrier): a push is a compare and two predicated stores, no atomics, no waits.
+//   barrier): a push is a compare and one predicated 8-byte store, no atomics, no waits.
 //   A full segment raises a flag: the tile is replayed in 4 sub-rounds (<= 8 pushes per
-//   segment each) with the affected queries compacted in between -- rank by counting over the
-//   <= 320 listed entries into a 64-entry "kept" area, segments emptied, thr raised to the k-th.
-//   Adversarial inputs (every tile beats the last) take the replay path every tile: slower,
-//   never wrong.
+//   segment each) with the affected queries compacted in between.  Compaction = one wave per
+//   query: keys staged in LDS, MSB-first radix select of the k-th key (skipped when <= 64 keys are
+//   staged), rank by counting among the selected, sorted write-back into a 64-entry "kept" area,
+//   segments emptied, thr raised to the k-th.  Adversarial inputs (every tile beats the last) take
+//   the replay path every tile: slower, never wrong.
+//
+// Main loop
+//   One barrier per K step.  The next stage's 8 LDS-DMA loads per wave are issued (inline asm, scalar
+//   base + 32-bit voffset) at the top of a step; fragment reads are software-pipelined over two
+//   register sets (the MFMAs of k-half 1 of the previous step run while the reads of this step's
+//   half 0 land); the first K step of a tile uses a zero C operand instead of cleared accumulators.
 #include "common.h"
 #include <type_traits>
 
