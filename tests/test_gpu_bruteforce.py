@@ -316,3 +316,24 @@ def test_device_merge_limits_are_loud():
         topk_merge_device(torch.zeros((65, 2, 4), device="cuda"), torch.zeros((65, 2, 4), dtype=torch.int64, device="cuda"))
     with pytest.raises(ValueError):
         topk_merge_device(torch.zeros((2, 2, 4)), torch.zeros((2, 2, 4), dtype=torch.int64))
+
+
+def test_random_shapes_fuzz():
+    """seeded sweep over ragged shapes: query counts around the 16 / 256 boundaries (online vs batch
+    kernel, partial query tiles), corpus sizes around tile and split boundaries, padded dims, every k regime."""
+    rng = np.random.default_rng(2024)
+    nqs = [1, 15, 16, 17, 255, 256, 257, 300, 513]
+    ns = [1, 7, 255, 256, 257, 2047, 2048, 2049, 5000, 9999, 33000]
+    ds_ = [8, 40, 64, 100, 128, 384]
+    ks = [1, 2, 7, 10, 15, 16, 17, 31, 33, 64]
+    for _ in range(28):
+        nq, n, d, k = (int(rng.choice(a)) for a in (nqs, ns, ds_, ks))
+        c16 = ds.normalize_round(ds.make_gaussian(n, d, int(rng.integers(1 << 30))))
+        q16 = ds.normalize_round(ds.make_gaussian(nq, d, int(rng.integers(1 << 30))))
+        ix = _index(c16)
+        try:
+            _check(ix, q16, c16, k)
+        except AssertionError as e:
+            raise AssertionError(f"shape nq={nq} n={n} d={d} k={k}: {e}") from e
+        finally:
+            ix.close()
