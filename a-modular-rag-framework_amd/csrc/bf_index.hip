@@ -471,6 +471,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   // One stage = 2*CPW LDS-DMA loads per wave (CPW corpus chunks, CPW query chunks), issued from inline
   // asm two at a time.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt
   // below.  M0 (LDS destination base) is written inside the statement that uses it and restored after.
+  f32x4 dbg_sink0 = {0.f, 0.f, 0.f, 0.f}, dbg_sink1 = {0.f, 0.f, 0.f, 0.f};   // diag 16384 only
   auto stage = [&](const char* a, const char* b, int buf) {
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
@@ -480,6 +481,13 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
         const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
         const char* c0 = base + (size_t)i * chunk_b;
         const char* c1 = c0 + chunk_b;
+        if (MRAG_DBG(16384) && (op == 1 || MRAG_DBG(32768))) {
+          // diag 16384: the same bytes by plain 16-byte loads into registers instead of LDS-DMA (loads-only
+          // timing: which side caps the 11.9 TB/s -- the request path or the LDS write side?); + 32768: both operands
+          dbg_sink0 += *(const f32x4*)(c0 + voff_e);   // compiler-visible loads: hipcc keeps the registers and counts the waits
+          dbg_sink1 += *(const f32x4*)(c1 + voff_o);
+          continue;
+        }
         uint32_t keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
@@ -908,6 +916,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     if (MRAG_DBG(1)) kstep_sync();
   }
 
+  if (MRAG_DBG(16384)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" :: "v"(dbg_sink0), "v"(dbg_sink1)); }
   __syncthreads();
 #ifdef MRAG_DIAG
   stamp_on = true;
