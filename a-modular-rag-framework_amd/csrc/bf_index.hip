@@ -284,39 +284,63 @@ __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, in
   if (lane < NGRP) scnt[q * NGRP + lane] = 0;
 }
 
-// End of the split: cut the lists of queries q0..q0+3 to their k best.  The accumulators are dead
-// here, so the 4 x 9 chunk loads of the four queries are all issued before any is used (one
-// memory latency per batch instead of one per chunk); entries below the query's final certified
-// threshold are dropped before ranking.
-__device__ __forceinline__ void tail_compact4(uint2* __restrict__ wg_list, int q0, int k, int lane,
-                                              uint64_t* __restrict__ scratch, const float (&thr)[4]) {
+// End of the split: cut the lists of queries q0..q0+3 to their k best.  A query's entries sit in up to
+// nine places (kept area + 8 segments, 576 slots) but number only a few dozen, so they are enumerated
+// DENSELY: entry e of query q lives in the place whose running count covers e.  One 8-byte load per lane
+// fetches the first 64 entries of a query (usually all of them); the loads of the four queries are issued
+// before any is used (the accumulators are dead here); entries below the query's final certified
+// threshold are dropped before ranking.  (Walking all nine 64-slot chunks per query made this tail 15 % of
+// the kernel at 125 k rows per GPU.)
+__device__ __forceinline__ int tail_slot(const int (&pre)[NGRP + 1], int e) {
+  // pre[0] = kept entries, pre[g+1] = pre[g] + entries of segment g; e < pre[NGRP]
+  int idx = e;                                    // inside the kept area
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g)
+    if (e >= pre[g]) idx = KEPT + g * SEG + (e - pre[g]);
+  return idx;
+}
+
+// NB queries per call.  Phase A (unrolled, small): one load per query into registers, then parked in
+// LDS (`park`, NB x 64 entries).  Phase B (a run-time loop, so the selection code exists once): prune,
+// stage keys, rank.  `scratch` = the 8-KiB rank_and_keep work area of this wave.
+template <int NB>
+__device__ __forceinline__ void tail_compact(uint2* __restrict__ wg_list, int q0, int k, int lane,
+                                             uint64_t* __restrict__ scratch, uint2* __restrict__ park, const float* thr_lds) {
   const int* kcnt = (const int*)(smem + OFF_KCNT);
   const int* scnt = (const int*)(smem + OFF_SCNT);
-  constexpr int R = QCAP / 64;
-  uint32_t sb[4][R], rw[4][R];
+  {
+    uint2 first[NB];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
+      const int q = q0 + u;
+      int pre[NGRP + 1];
+      pre[0] = kcnt[q];
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) pre[g + 1] = pre[g] + min(scnt[q * NGRP + g], SEG);
+      first[u] = make_uint2(0u, 0u);
+      if (lane < pre[NGRP]) first[u] = wg_list[(size_t)q * QCAP + tail_slot(pre, lane)];
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) park[u * 64 + lane] = first[u];
+  }
+#pragma unroll 1
+  for (int u = 0; u < NB; ++u) {
     const int q = q0 + u;
     const uint2* lst = wg_list + (size_t)q * QCAP;
-    const int kc = kcnt[q];
+    int pre_u[NGRP + 1];
+    pre_u[0] = kcnt[q];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int idx = r * 64 + lane;
-      const bool ok = idx < KEPT ? idx < kc : ((idx - KEPT) & (SEG - 1)) < min(scnt[q * NGRP + ((idx - KEPT) / SEG)], SEG);
-      sb[u][r] = 0xFF800000u;   // -inf: fails every '>= thr' test below unless thr is -inf ...
-      rw[u][r] = 0xFFFFFFFFu;   // ... in which case this marker row says "not an entry"
-      if (ok) { const uint2 e = lst[idx]; sb[u][r] = e.x; rw[u][r] = e.y; }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int q = q0 + u;
+    for (int g = 0; g < NGRP; ++g) pre_u[g + 1] = pre_u[g] + min(scnt[q * NGRP + g], SEG);
+    const int n_ent = pre_u[NGRP];
+    const float th = thr_lds[q];
     int total = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const bool valid = rw[u][r] != 0xFFFFFFFFu && __uint_as_float(sb[u][r]) >= thr[u];
+    for (int base = 0; base < n_ent; base += 64) {
+      const int e = base + lane;
+      uint2 en = park[u * 64 + lane];
+      if (base > 0 && e < n_ent) en = lst[tail_slot(pre_u, e)];
+      const bool valid = e < n_ent && __uint_as_float(en.x) >= th;
       const unsigned long long bal = __ballot(valid);
-      if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = make_key(sb[u][r], rw[u][r]);
+      if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = make_key(en.x, en.y);
       total += __popcll(bal);
     }
     rank_and_keep(wg_list + (size_t)q * QCAP, q, k, lane, scratch, total);
@@ -898,12 +922,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
         // (the accumulators are dead here: the batched-load form used at the end of the split fits)
         uint64_t* scr = (uint64_t*)(smem + (buf ^ 1) * STAGE_BYTES + w * 8192);
 #pragma unroll 1
-        for (int qq = 0; qq < QPW; qq += 4) {
-          float t4[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) t4[u] = tau_c[w * QPW + qq + u];
-          tail_compact4(wg_list, w * QPW + qq, p.k, elane, scr, t4);
-        }
+        // (work area + parking: this wave's 8 KiB of the consumed stage buffer; 4 queries per pass keep the parking at 2 KiB)
+        for (int qq = 0; qq < QPW; qq += 4)
+          tail_compact<4>(wg_list, w * QPW + qq, p.k, elane, scr, (uint2*)(scr + 768), tau_c);
       }
       MRAG_STAMP(14 + (ti == 0 ? 0 : 100));
       if (resync) __syncthreads();
@@ -928,16 +949,15 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   if (n_tiles > 0 && !MRAG_DBG(2048)) {   // dbg 2048: ablate the end-of-split compaction
     const uint32_t* stat_last = stat + ((n_tiles - 1) & 1) * TQ;
     uint64_t* scratch = (uint64_t*)(smem + w * 8192);
-    for (int qq = 0; qq < QPW; qq += 4) {
-      float thr_f[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = w * QPW + qq + u;
-        thr_f[u] = tau_c[q];
-        if (p.k <= K_CERT) thr_f[u] = fmaxf(thr_f[u], ord_f32(stat_last[q]));
-      }
-      tail_compact4(wg_list, w * QPW + qq, p.k, lane, scratch, thr_f);
+    // 16 queries per pass: two memory latencies per wave for its 32 lists (they are spread over GBs of
+    // list space, i.e. they come from HBM).  Both stage buffers are free here: per wave 8 KiB work area
+    // + 8 KiB of parking.  The final thresholds go through the (now idle) tau_c words.
+    if (p.k <= K_CERT) {
+      for (int i = lane; i < QPW; i += 64) { const int q = w * QPW + i; tau_c[q] = fmaxf(tau_c[q], ord_f32(stat_last[q])); }
     }
+    constexpr int TB = 16;
+    uint2* park = (uint2*)(smem + NW * 8192 + w * 8192);
+    for (int qq = 0; qq < QPW; qq += TB) tail_compact<TB>(wg_list, w * QPW + qq, p.k, lane, scratch, park, tau_c);
   }
   __syncthreads();
   MRAG_STAMP(99);
