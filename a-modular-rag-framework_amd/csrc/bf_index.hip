@@ -207,6 +207,7 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 // entries was ~20 000 at 576 entries, which made k > 16 -- no row-count certificate, thresholds
 // driven by compaction alone -- 3-5x slower than k <= 16).
 // scratch layout (8 KiB per wave): keys[QCAP] u64 | hist[256] u32 | sel[KMAX] u64
+template <bool WIDE = false>   // WIDE: eight candidate reads in flight in the ranking loop (16 more VGPRs: end-of-split tail only)
 __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, int k, int lane,
                                               uint64_t* __restrict__ scratch, int total) {
   float* tau_c = (float*)(smem + OFF_TAU);
@@ -274,7 +275,19 @@ __device__ __forceinline__ void rank_and_keep(uint2* __restrict__ lst, int q, in
   __builtin_amdgcn_wave_barrier();
   const uint64_t my = lane < nsel ? cand[lane] : 0ull;
   int rank = 0;
-  for (int j = 0; j < nsel; ++j) rank += (cand[j] > my) ? 1 : 0;
+  // eight broadcast reads in flight per step (one at a time, every step waits out an LDS round trip);
+  // slots past nsel hold stale keys: masked by the index test
+  if constexpr (WIDE) {
+    for (int j0 = 0; j0 < nsel; j0 += 8) {
+      uint64_t c8[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) c8[t] = cand[(j0 + t) & 63];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) rank += (j0 + t < nsel && c8[t] > my) ? 1 : 0;
+    }
+  } else {
+    for (int j = 0; j < nsel; ++j) rank += (cand[j] > my) ? 1 : 0;
+  }
   if (lane < nsel && rank < k) {
     const uint32_t sb = __float_as_uint(ord_f32((uint32_t)(my >> 32)));
     lst[rank] = make_uint2(sb, 0xFFFFFFFFu - (uint32_t)my);
@@ -303,10 +316,12 @@ __device__ __forceinline__ int tail_slot(const int (&pre)[NGRP + 1], int e) {
 // NB queries per call.  Phase A (unrolled, small): one load per query into registers, then parked in
 // LDS (`park`, NB x 64 entries).  Phase B (a run-time loop, so the selection code exists once): prune,
 // stage keys, rank.  `scratch` = the 8-KiB rank_and_keep work area of this wave.
-template <int NB>
+template <int NB, bool WIDE = false>
 __device__ __forceinline__ void tail_compact(uint2* __restrict__ wg_list, int q0, int k, int lane,
-                                             uint64_t* __restrict__ scratch, uint2* __restrict__ park, const float* thr_lds) {
+                                             uint64_t* __restrict__ scratch, uint2* __restrict__ park, const float* thr_lds,
+                                             long long* dbg_t = nullptr) {
   const int* kcnt = (const int*)(smem + OFF_KCNT);
+  if (dbg_t) dbg_t[0] = (long long)__builtin_readcyclecounter();
   const int* scnt = (const int*)(smem + OFF_SCNT);
   {
     uint2 first[NB];
@@ -320,8 +335,10 @@ __device__ __forceinline__ void tail_compact(uint2* __restrict__ wg_list, int q0
       first[u] = make_uint2(0u, 0u);
       if (lane < pre[NGRP]) first[u] = wg_list[(size_t)q * QCAP + tail_slot(pre, lane)];
     }
+    if (dbg_t) dbg_t[1] = (long long)__builtin_readcyclecounter();
 #pragma unroll
     for (int u = 0; u < NB; ++u) park[u * 64 + lane] = first[u];
+    if (dbg_t) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbg_t[2] = (long long)__builtin_readcyclecounter(); }
   }
 #pragma unroll 1
   for (int u = 0; u < NB; ++u) {
@@ -334,17 +351,29 @@ __device__ __forceinline__ void tail_compact(uint2* __restrict__ wg_list, int q0
     const int n_ent = pre_u[NGRP];
     const float th = thr_lds[q];
     int total = 0;
-    for (int base = 0; base < n_ent; base += 64) {
+    {   // entries 0..63: parked in LDS by phase A.  (Kept apart from the global loads below: merged into one
+        // loop hipcc selects between the two POINTERS and issues a flat load, whose wait also covers the
+        // previous query's stores -- 2 000 cycles per query.)
+      const uint2 en = park[u * 64 + lane];
+      const bool valid = lane < n_ent && __uint_as_float(en.x) >= th;
+      const unsigned long long bal = __ballot(valid);
+      if (valid) scratch[__popcll(bal & ((1ull << lane) - 1ull))] = make_key(en.x, en.y);
+      total = __popcll(bal);
+    }
+    for (int base = 64; base < n_ent; base += 64) {
       const int e = base + lane;
-      uint2 en = park[u * 64 + lane];
-      if (base > 0 && e < n_ent) en = lst[tail_slot(pre_u, e)];
+      uint2 en = make_uint2(0u, 0u);
+      if (e < n_ent) en = lst[tail_slot(pre_u, e)];
       const bool valid = e < n_ent && __uint_as_float(en.x) >= th;
       const unsigned long long bal = __ballot(valid);
       if (valid) scratch[total + __popcll(bal & ((1ull << lane) - 1ull))] = make_key(en.x, en.y);
       total += __popcll(bal);
     }
-    rank_and_keep(wg_list + (size_t)q * QCAP, q, k, lane, scratch, total);
+    if (dbg_t && u < 4) dbg_t[3 + 2 * u] = (long long)__builtin_readcyclecounter();
+    rank_and_keep<WIDE>(wg_list + (size_t)q * QCAP, q, k, lane, scratch, total);
+    if (dbg_t && u < 4) dbg_t[4 + 2 * u] = (long long)__builtin_readcyclecounter();
   }
+  if (dbg_t) dbg_t[11] = (long long)__builtin_readcyclecounter();
 }
 
 __device__ __forceinline__ void compact_query(uint2* __restrict__ lst, int q, int k,
@@ -957,7 +986,15 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     }
     constexpr int TB = 16;
     uint2* park = (uint2*)(smem + NW * 8192 + w * 8192);
-    for (int qq = 0; qq < QPW; qq += TB) tail_compact<TB>(wg_list, w * QPW + qq, p.k, lane, scratch, park, tau_c);
+#ifdef MRAG_DIAG
+    long long tt[12] = {0};
+    for (int qq = 0; qq < QPW; qq += TB)
+      tail_compact<TB, true>(wg_list, w * QPW + qq, p.k, lane, scratch, park, tau_c, (((MRAG_DIAG) & 16) && qq == 0) ? tt : nullptr);
+    if (((MRAG_DIAG) & 16) && blockIdx.x == 0 && tid == 0 && p.stamps)
+      for (int i = 0; i < 12; ++i) p.stamps[100 + i] = tt[i] - tt[0];
+#else
+    for (int qq = 0; qq < QPW; qq += TB) tail_compact<TB, true>(wg_list, w * QPW + qq, p.k, lane, scratch, park, tau_c);
+#endif
   }
   __syncthreads();
   MRAG_STAMP(99);
@@ -1489,6 +1526,8 @@ int bf_launch(const BfLaunch& a) {
       long long hs[128];
       MRAG_HIP(hipStreamSynchronize(stream));
       MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[mrag tail] first pass of 16 queries, cycles from its start: loads issued %lld, parked %lld; query 0 staged %lld ranked %lld; q1 %lld %lld; q2 %lld %lld; q3 %lld %lld; pass done %lld\n",
+              hs[101], hs[102], hs[103], hs[104], hs[105], hs[106], hs[107], hs[108], hs[109], hs[110], hs[111]);
       fprintf(stderr, "[mrag stamps]");
       for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i) fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
       fprintf(stderr, "\n");
