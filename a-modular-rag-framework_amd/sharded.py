@@ -19,6 +19,19 @@ import numpy as np
 from .index import topk_merge, topk_merge_device
 
 
+def _host_pair(bufs: dict, q: int, k: int):
+    """Pinned host result buffers, two sets used alternately: the arrays a call returns are views of
+    pinned memory and stay valid until the call AFTER the next one (no per-call allocation or copy)."""
+    import torch
+    if bufs.get("hkey") != (q, k):
+        bufs["hkey"] = (q, k)
+        bufs["hring"] = [(torch.empty((q, k), dtype=torch.float32, pin_memory=True),
+                          torch.empty((q, k), dtype=torch.int64, pin_memory=True)) for _ in range(2)]
+        bufs["hturn"] = 0
+    bufs["hturn"] ^= 1
+    return bufs["hring"][bufs["hturn"]]
+
+
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of ``rank``: [lo, hi)."""
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
@@ -32,7 +45,8 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
     ``local_scores`` [Q,k] float32 and ``local_ids`` [Q,k] int64 are torch tensors on the
     backend's device (CUDA for nccl, CPU for gloo).  Every rank returns the full merged
     (scores [Q,k] float32, ids [Q,k] int64) as numpy arrays.  ``bufs`` (a dict the caller
-    keeps) caches the gather / pinned staging buffers across calls."""
+    keeps) caches the gather / pinned staging buffers across calls; with CUDA inputs the returned
+    arrays are views of pinned buffers that stay valid until the call after the next one."""
     import torch
     import torch.distributed as dist
 
@@ -44,14 +58,11 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
             return (local_scores.detach().numpy().astype(np.float32, copy=False),
                     local_ids.detach().numpy().astype(np.int64, copy=False))
         # one pinned D2H per array + one stream sync (pageable .cpu() costs two blocking staged copies)
-        if bufs.get("key1") != (q, k):
-            bufs["key1"] = (q, k)
-            bufs["h1s"] = torch.empty((q, k), dtype=torch.float32, pin_memory=True)
-            bufs["h1i"] = torch.empty((q, k), dtype=torch.int64, pin_memory=True)
-        bufs["h1s"].copy_(local_scores, non_blocking=True)
-        bufs["h1i"].copy_(local_ids, non_blocking=True)
+        hs, hi = _host_pair(bufs, q, k)
+        hs.copy_(local_scores, non_blocking=True)
+        hi.copy_(local_ids, non_blocking=True)
         torch.cuda.current_stream(local_scores.device).synchronize()
-        return bufs["h1s"].numpy().copy(), bufs["h1i"].numpy().copy()
+        return hs.numpy(), hi.numpy()
     key = (world, q, k, str(local_scores.device))
     if bufs.get("key") != key:
         bufs.clear()
@@ -74,16 +85,16 @@ def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0) -
     if gs.is_cuda:
         on_device = merge == "device" or (merge == "auto" and world <= 64 and world * k <= 2048)
         if on_device:
-            if "ms" not in bufs:
+            if bufs.get("mkey") != (q, k):
+                bufs["mkey"] = (q, k)
                 bufs["ms"] = torch.empty((q, k), dtype=torch.float32, device=gs.device)
                 bufs["mi"] = torch.empty((q, k), dtype=torch.int64, device=gs.device)
-                bufs["hms"] = torch.empty((q, k), dtype=torch.float32, pin_memory=True)
-                bufs["hmi"] = torch.empty((q, k), dtype=torch.int64, pin_memory=True)
             topk_merge_device(gs, gi, bufs["ms"], bufs["mi"])
-            bufs["hms"].copy_(bufs["ms"], non_blocking=True)
-            bufs["hmi"].copy_(bufs["mi"], non_blocking=True)
+            hs, hi = _host_pair(bufs, q, k)
+            hs.copy_(bufs["ms"], non_blocking=True)
+            hi.copy_(bufs["mi"], non_blocking=True)
             torch.cuda.current_stream(gs.device).synchronize()
-            return bufs["hms"].numpy().copy(), bufs["hmi"].numpy().copy()
+            return hs.numpy(), hi.numpy()
         if "hs" not in bufs:
             bufs["hs"] = torch.empty((world, q, k), dtype=torch.float32, pin_memory=True)
             bufs["hi"] = torch.empty((world, q, k), dtype=torch.int64, pin_memory=True)
