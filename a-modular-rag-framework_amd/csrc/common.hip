@@ -1,5 +1,6 @@
 // Library plumbing: error strings, handle registry, device selection, row preparation (K1).
 #include "common.h"
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
@@ -143,11 +144,70 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const SRC* __restrict__ 
   }
 }
 
+// fp32 sources with dim % 8 == 0 and ld <= 4096: one wave per row, the row is read ONCE as 2 x 16-byte
+// loads per 8-element chunk (chunk c of lane l: c = l, l + 64, ...) and kept in registers for the fp64
+// sum of squares and the division; stores are 16 bytes.  Same arithmetic as the scalar kernel (fp64
+// square sum in the same per-lane order is NOT kept: the order of the partial sums differs, the fp64
+// sum is then rounded once -- see the parity test on device normalisation).
+template <typename DST>
+__global__ __launch_bounds__(256) void prep_rows_vec_kernel(const float* __restrict__ src, int64_t n, int dim,
+                                                            DST* __restrict__ dst, int ld, int normalize) {
+  typedef DST d8 __attribute__((ext_vector_type(8)));
+  constexpr int MAXC = 8;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float4* s = (const float4*)(src + row * (int64_t)dim);
+  d8* d = (d8*)(dst + row * (int64_t)ld);
+  const int nch = dim >> 3, nch_out = ld >> 3;
+  float v[MAXC][8];
+  double ss = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 a = s[2 * c], b = s[2 * c + 1];
+      v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += (double)v[i][j] * (double)v[i][j];
+    }
+  }
+  double inv = 1.0;
+  if (normalize) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    inv = ss > 0.0 ? sqrt(ss) : 1.0;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch_out) {
+      d8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = 0.f;
+        if (c < nch) y = normalize ? (float)((double)v[i][j] / inv) : v[i][j];
+        o[j] = (DST)y;
+      }
+      d[c] = o;
+    }
+  }
+}
+
 template <typename SRC>
 static int prep_dispatch_dst(const void* src, int64_t n, int dim, void* dst, int ld, int storage_dtype,
                              int normalize, hipStream_t stream) {
   if (n == 0) return MRAG_OK;
   dim3 grid((unsigned)((n + 3) / 4)), block(256);
+  if (std::is_same<SRC, float>::value && dim % 8 == 0 && ld % 8 == 0 && ld <= 4096 && ((uintptr_t)src & 15) == 0 &&
+      (storage_dtype == MRAG_F16 || storage_dtype == MRAG_BF16)) {
+    if (storage_dtype == MRAG_F16)
+      hipLaunchKernelGGL((prep_rows_vec_kernel<_Float16>), grid, block, 0, stream, (const float*)src, n, dim, (_Float16*)dst, ld, normalize);
+    else
+      hipLaunchKernelGGL((prep_rows_vec_kernel<__bf16>), grid, block, 0, stream, (const float*)src, n, dim, (__bf16*)dst, ld, normalize);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  }
   if (storage_dtype == MRAG_F16) {
     hipLaunchKernelGGL((prep_rows_kernel<SRC, _Float16>), grid, block, 0, stream, (const SRC*)src, n, dim,
                        (_Float16*)dst, ld, normalize);
