@@ -38,7 +38,7 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, bufs: Optional[dict] = None,
-                     merge: str = "auto") -> Tuple[np.ndarray, np.ndarray]:
+                     merge: str = "auto", force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """All-gather the per-shard partial top-k and merge.  ``merge``: "host" (mrag_topk_merge),
     "device" (mrag_topk_merge_device, CUDA tensors only) or "auto" (device when it applies).
 
@@ -53,7 +53,7 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     q, k = local_scores.shape
     bufs = bufs if bufs is not None else {}
-    if world == 1:
+    if world == 1 and not force_collective:   # (force_collective: run the all-gather + merge even alone -- tests)
         if not local_scores.is_cuda:
             return (local_scores.detach().numpy().astype(np.float32, copy=False),
                     local_ids.detach().numpy().astype(np.int64, copy=False))
@@ -136,9 +136,11 @@ class ShardedDenseIndex:
         if len(self.index) > self.hi - self.lo:
             raise ValueError("more rows than this shard owns")
 
-    def search(self, queries, k: int, nthreads: int = 0, merge: str = "auto", **kw) -> Tuple[np.ndarray, np.ndarray]:
+    def search(self, queries, k: int, nthreads: int = 0, merge: str = "auto", force_collective: bool = False,
+               **kw) -> Tuple[np.ndarray, np.ndarray]:
         sc, ids = self._local_search(queries, k, **kw)
         import torch
         if not torch.is_tensor(sc):
             sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
-        return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge)
+        return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
+                                force_collective=force_collective)

@@ -102,3 +102,30 @@ def test_c3_encoder_batch_matches_oracle_subsample():
     # batch composition does not change a row (padding rows are masked out)
     again = enc.forward(ids[sub], mask[sub], pool="cls")
     np.testing.assert_allclose(again, out[sub], rtol=0, atol=2e-4)
+
+
+def test_rccl_exchange_path_single_rank():
+    """The N > 1 exchange on the GPU with the real backend: an RCCL process group of ONE rank forced through
+    all_gather_into_tensor + the device / host merge must return the plain single-index result."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mrag_amd.sharded import ShardedDenseIndex
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, d, nq, k = 40_000, 256, 700, 10
+        sh = ShardedDenseIndex(d, n, rank=0, world=1, device=0)
+        sh.add_local(_gpu_corpus(n, d, 31))
+        q = _gpu_corpus(nq, d, 32)
+        ref_s, ref_i = sh.search(q, k)
+        ref_s, ref_i = ref_s.copy(), ref_i.copy()
+        for mode in ("device", "host"):
+            s_, i_ = sh.search(q, k, merge=mode, force_collective=True)
+            assert (i_ == ref_i).all() and np.array_equal(s_, ref_s), mode
+    finally:
+        if created:
+            dist.destroy_process_group()
