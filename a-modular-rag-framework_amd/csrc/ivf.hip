@@ -34,9 +34,10 @@ struct IvfIndex : Object {
   int64_t n_sorted = 0;
   std::vector<int> list_tile_lo, list_count;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
+  DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
   ~IvfIndex() override {
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
-    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts}) b->release();
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan}) b->release();
   }
 };
 
@@ -52,6 +53,79 @@ __global__ void gather_rows_kernel(const uint16_t* __restrict__ src, const int64
   const uint4* sp = (const uint4*)(src + (size_t)(s < 0 ? 0 : s) * ld);
   uint4* dp = (uint4*)(dst + (size_t)r * ld);
   for (int i = lane; i < ld / 8; i += 64) dp[i] = s < 0 ? make_uint4(0, 0, 0, 0) : sp[i];
+}
+
+// ---- search-time regrouping on the device: list -> the (query, probe) pairs that hit it -------------
+// probes [npairs] = list id per (query, probe slot) (< 0: none).  Pass 1 counts the pairs per list;
+// pass 2 (one block) turns the counts into "first workgroup of the list" (256 queries per workgroup)
+// and writes the workgroup descriptors; pass 3 hands every pair its (workgroup, slot) with an atomic
+// cursor per list.  The slot order inside a list depends on the atomics' order, the results do not:
+// every (query, row) score is computed the same way whichever slot the query sits in.
+__global__ void ivf_count_kernel(const int64_t* __restrict__ probes, int64_t npairs, const int* __restrict__ list_count,
+                                 int* __restrict__ lcount) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npairs) return;
+  const int64_t l = probes[i];
+  if (l >= 0 && list_count[l] > 0) atomicAdd(&lcount[l], 1);
+}
+
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
+                                                        const int* __restrict__ list_tile_lo, int nlist,
+                                                        int* __restrict__ wg_first, int* __restrict__ cursor,
+                                                        int* __restrict__ desc, int desc_cap, int* __restrict__ n_wg_out) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nlist; base += 1024) {
+    const int l = base + tid;
+    const int cnt = l < nlist ? lcount[l] : 0;
+    const int nt = (cnt + 255) >> 8;
+    part[tid] = nt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // inclusive scan (Hillis-Steele)
+      const int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    const int first = carry + part[tid] - nt;
+    if (l < nlist) {
+      wg_first[l] = first;
+      cursor[l] = 0;
+      const int tlo = list_tile_lo[l], lc = list_count[l];
+      for (int c = 0; c < nt; ++c) {
+        const int wgi = first + c;
+        if (wgi < desc_cap) {
+          int* d = desc + (size_t)wgi * 8;
+          d[0] = wgi * 256;
+          d[1] = min(256, cnt - c * 256);
+          d[2] = tlo;
+          d[3] = tlo + ((lc + 255) >> 8);
+          d[4] = tlo * 256 + lc;
+          d[5] = 0; d[6] = 0; d[7] = 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) *n_wg_out = carry;
+}
+
+__global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
+                                   const int* __restrict__ list_count, const int* __restrict__ wg_first,
+                                   int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npairs) return;
+  const int64_t l = probes[i];
+  if (l < 0 || list_count[l] == 0) { ploc[i] = make_int2(-1, 0); return; }
+  const int pos = atomicAdd(&cursor[l], 1);
+  const int wgi = wg_first[l] + (pos >> 8), slot = pos & 255;
+  gq[(size_t)wgi * 256 + slot] = i / nprobe;
+  ploc[i] = make_int2(wgi, slot);
 }
 
 __global__ void ids_to_i32_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ out) {
@@ -166,6 +240,10 @@ static int ivf_finalize(IvfIndex* ix, hipStream_t stream) {
   MRAG_HIP(hipMemcpyAsync(ix->row_ids, perm.data(), (size_t)ns * 8, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, stream, ix->raw ? ix->raw : ix->sorted, ix->row_ids, ns, ix->ld, ix->sorted);
   MRAG_HIP(hipGetLastError());
+  MRAG_TRY(ix->d_list_count.ensure((size_t)ix->nlist * 4));
+  MRAG_TRY(ix->d_list_tile_lo.ensure((size_t)ix->nlist * 4));
+  MRAG_HIP(hipMemcpyAsync(ix->d_list_count.p, ix->list_count.data(), (size_t)ix->nlist * 4, hipMemcpyHostToDevice, stream));
+  MRAG_HIP(hipMemcpyAsync(ix->d_list_tile_lo.p, ix->list_tile_lo.data(), (size_t)ix->nlist * 4, hipMemcpyHostToDevice, stream));
   MRAG_HIP(hipStreamSynchronize(stream));
   ix->n_sorted = ns;
   ix->dirty = false;
@@ -396,55 +474,36 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
     MRAG_TRY(bf_launch(a));
   }
-  std::vector<int64_t> probes((size_t)nq * nprobe);
-  MRAG_HIP(hipMemcpyAsync(probes.data(), ix->tmp_id.p, probes.size() * 8, hipMemcpyDeviceToHost, stream));
-  MRAG_HIP(hipStreamSynchronize(stream));
-  // 2) host: list -> the queries that probe it (counting sort), cut into workgroups of <= 256 queries
+  // 2) device: list -> the queries that probe it, cut into workgroups of <= 256 queries (kernels above).
+  //    Only the workgroup count comes back to the host (4 bytes) -- it sizes the gather and the grid.
   const size_t npairs = (size_t)nq * nprobe;
-  std::vector<int> lcount(ix->nlist + 1, 0);
-  for (size_t i = 0; i < npairs; ++i) {
-    const int64_t l = probes[i];
-    if (l >= 0 && ix->list_count[l] > 0) ++lcount[l + 1];
-  }
-  std::vector<int> wg_first(ix->nlist + 1, 0);     // first workgroup of each list
-  for (int l = 0; l < ix->nlist; ++l) wg_first[l + 1] = wg_first[l] + (lcount[l + 1] + 255) / 256;
-  const int n_wg = wg_first[ix->nlist];
-  std::vector<int> desc((size_t)n_wg * 8, 0);      // 8 ints per workgroup
-  std::vector<int64_t> gq((size_t)n_wg * 256, -1); // query row feeding each of the 256 slots (-1 = zero row)
-  std::vector<int> ploc(npairs * 2, 0);
-  for (size_t i = 0; i < npairs; ++i) ploc[2 * i] = -1;
-  std::vector<int> cursor(ix->nlist, 0);
-  for (int64_t q = 0; q < nq; ++q)                 // queries ascend inside every list -> deterministic slots
-    for (int pi = 0; pi < nprobe; ++pi) {
-      const size_t i = (size_t)q * nprobe + pi;
-      const int64_t l = probes[i];
-      if (l < 0 || ix->list_count[l] == 0) continue;
-      const int pos = cursor[l]++;
-      const int wgi = wg_first[l] + (pos >> 8), slot = pos & 255;
-      gq[(size_t)wgi * 256 + slot] = q;
-      ploc[2 * i] = wgi;
-      ploc[2 * i + 1] = slot;
-    }
-  for (int l = 0; l < ix->nlist; ++l) {
-    const int cnt_l = lcount[l + 1];
-    for (int c0 = 0, wgi = wg_first[l]; c0 < cnt_l; c0 += 256, ++wgi) {
-      int* d = &desc[(size_t)wgi * 8];
-      d[0] = wgi * 256;
-      d[1] = std::min(256, cnt_l - c0);
-      d[2] = ix->list_tile_lo[l];
-      d[3] = ix->list_tile_lo[l] + (ix->list_count[l] + 255) / 256;
-      d[4] = ix->list_tile_lo[l] * 256 + ix->list_count[l];
-    }
-  }
+  const int nl = ix->nlist;
+  const int64_t wg_bound = (int64_t)std::min<size_t>((size_t)nl, npairs) + (int64_t)(npairs / 256) + 1;
+  MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
+  int* d_lcount = (int*)ix->plan.p;
+  int* d_wg_first = d_lcount + nl;
+  int* d_cursor = d_wg_first + nl;
+  int* d_nwg = d_cursor + nl;
+  MRAG_TRY(ix->desc.ensure((size_t)wg_bound * 8 * 4));
+  MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
+  MRAG_TRY(ix->ploc.ensure(npairs * 8));
+  MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
+  MRAG_HIP(hipMemsetAsync(ix->gq.p, 0xFF, (size_t)wg_bound * 256 * 8, stream));
+  const unsigned pgrid = (unsigned)((npairs + 255) / 256);
+  hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
+                     (const int*)ix->d_list_count.p, d_lcount);
+  hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
+                     (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
+  hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
+                     (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p);
+  MRAG_HIP(hipGetLastError());
+  int n_wg = 0;
+  MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
+  if (n_wg < 0 || n_wg > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", n_wg, (long long)wg_bound);
   // 3) gather queries per workgroup, scan the lists, merge
-  MRAG_TRY(ix->ploc.ensure(ploc.size() * 4));
-  MRAG_HIP(hipMemcpyAsync(ix->ploc.p, ploc.data(), ploc.size() * 4, hipMemcpyHostToDevice, stream));
   if (n_wg) {
-    MRAG_TRY(ix->desc.ensure(desc.size() * 4));
-    MRAG_TRY(ix->gq.ensure(gq.size() * 8));
     MRAG_TRY(ix->qg.ensure((size_t)n_wg * 256 * ix->ld * 2));
-    MRAG_HIP(hipMemcpyAsync(ix->desc.p, desc.data(), desc.size() * 4, hipMemcpyHostToDevice, stream));
-    MRAG_HIP(hipMemcpyAsync(ix->gq.p, gq.data(), gq.size() * 8, hipMemcpyHostToDevice, stream));
     const int64_t ng = (int64_t)n_wg * 256;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)ix->qbuf.p,
                        (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p);
