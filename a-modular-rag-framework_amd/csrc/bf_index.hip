@@ -349,6 +349,7 @@ __device__ __forceinline__ void tail_compact(uint2* __restrict__ wg_list, int q0
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) pre_u[g + 1] = pre_u[g] + min(scnt[q * NGRP + g], SEG);
     const int n_ent = pre_u[NGRP];
+    if (n_ent == 0) continue;   // nothing listed (padding query of a partial tile / IVF group): counts are already zero
     const float th = thr_lds[q];
     int total = 0;
     {   // entries 0..63: parked in LDS by phase A.  (Kept apart from the global loads below: merged into one
@@ -427,7 +428,9 @@ __device__ __forceinline__ void compact_owned(uint2* __restrict__ wg_list, int w
 
 // NF = 16-query column groups per wave: 4 -> 8 waves (2 x 4) of 128 x 64, two per SIMD, 256 VGPRs each;
 //                                        8 -> 4 waves (2 x 2) of 128 x 128, ONE per SIMD, 512 VGPRs each
-template <int DT, int NF>
+// DESC: descriptor mode (IVF list scan) -- its block decoding and its partial-query-tile loads exist only in that
+// instance, the dense (t, s) instance carries neither.
+template <int DT, int NF, bool DESC>
 __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_topk_kernel(BfParams p) {
   constexpr int WN = 16 / NF;            // waves along the query dimension
   constexpr int NW = 2 * WN;             // waves per workgroup
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 
   // ---- block -> (query tile, corpus tile range) ----------------------------------------------
   int wg, q_row0, nq_local, tile_lo, tile_hi, rows_end;
-  if (p.wg_desc) {
+  if (DESC) {
     // descriptor mode: one workgroup = one IVF list x up to 256 of the queries that probe it
     const int* d = p.wg_desc + (size_t)blockIdx.x * 8;
     wg = blockIdx.x;
@@ -531,6 +534,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
       const char* base = op ? b : a;
 #pragma unroll
       for (int i = 0; i < CPW; i += 2) {
+        // query rows past the tile's valid queries are never loaded (their thresholds are +inf, whatever the
+        // stale LDS bytes score): an IVF group averages ~80 of 256 queries, the last tile of a batch fewer
+        if (DESC && op == 1 && (CPW * w + i) * 8 >= nq_local) continue;
         const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
         const char* c0 = base + (size_t)i * chunk_b;
         const char* c1 = c0 + chunk_b;
@@ -1406,15 +1412,16 @@ constexpr int MAX_QTILES_PER_LAUNCH = 64;
 // hipcc's allocation of the 256-AGPR tile spills into the K loop (98 ms vs 13.6 ms, round-1 measurement).
 static int launch_k2(int dtype, size_t grid, hipStream_t stream, const BfParams& p) {
   typedef void (*K2Fn)(BfParams);
-  static const K2Fn fns[2] = {bf_gemm_topk_kernel<MRAG_F16, 4>, bf_gemm_topk_kernel<MRAG_BF16, 4>};
-  static bool attr_done[2] = {false, false};
-  const int di = dtype == MRAG_F16 ? 0 : 1;
-  if (!attr_done[di]) {
-    MRAG_HIP(hipFuncSetAttribute((const void*)fns[di], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_done[di] = true;
+  static const K2Fn fns[2][2] = {{bf_gemm_topk_kernel<MRAG_F16, 4, false>, bf_gemm_topk_kernel<MRAG_F16, 4, true>},
+                                 {bf_gemm_topk_kernel<MRAG_BF16, 4, false>, bf_gemm_topk_kernel<MRAG_BF16, 4, true>}};
+  static bool attr_done[2][2] = {};
+  const int di = dtype == MRAG_F16 ? 0 : 1, de = p.wg_desc ? 1 : 0;
+  if (!attr_done[di][de]) {
+    MRAG_HIP(hipFuncSetAttribute((const void*)fns[di][de], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr_done[di][de] = true;
   }
   if (!grid) return MRAG_OK;
-  hipLaunchKernelGGL(fns[di], dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
+  hipLaunchKernelGGL(fns[di][de], dim3((unsigned)grid), dim3(NTHR), LDS_TOTAL, stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }

@@ -44,12 +44,13 @@ struct IvfIndex : Object {
 static size_t esize(int dt) { return dt == MRAG_F32 ? 4 : dt == MRAG_F64 ? 8 : (dt == MRAG_F16 || dt == MRAG_BF16) ? 2 : 0; }
 
 __global__ void gather_rows_kernel(const uint16_t* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int ld,
-                                   uint16_t* __restrict__ dst) {
+                                   uint16_t* __restrict__ dst, int zero_fill) {
   // one wave per destination row; idx < 0 -> zero row
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int64_t s = idx[r];
+  if (s < 0 && !zero_fill) return;   // search-time query slabs: rows past a group's queries are never read
   const uint4* sp = (const uint4*)(src + (size_t)(s < 0 ? 0 : s) * ld);
   uint4* dp = (uint4*)(dst + (size_t)r * ld);
   for (int i = lane; i < ld / 8; i += 64) dp[i] = s < 0 ? make_uint4(0, 0, 0, 0) : sp[i];
@@ -238,7 +239,7 @@ static int ivf_finalize(IvfIndex* ix, hipStream_t stream) {
   MRAG_HIP(hipMalloc((void**)&ix->sorted, (size_t)ns * ix->ld * 2));
   MRAG_HIP(hipMalloc((void**)&ix->row_ids, (size_t)ns * 8));
   MRAG_HIP(hipMemcpyAsync(ix->row_ids, perm.data(), (size_t)ns * 8, hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, stream, ix->raw ? ix->raw : ix->sorted, ix->row_ids, ns, ix->ld, ix->sorted);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, stream, ix->raw ? ix->raw : ix->sorted, ix->row_ids, ns, ix->ld, ix->sorted, 1);
   MRAG_HIP(hipGetLastError());
   MRAG_TRY(ix->d_list_count.ensure((size_t)ix->nlist * 4));
   MRAG_TRY(ix->d_list_tile_lo.ensure((size_t)ix->nlist * 4));
@@ -357,7 +358,7 @@ int mrag_ivf_train(mrag_handle h, const void* rows, int64_t n, int src_dtype, in
   hipError_t e = hipMemcpyAsync(dpick.p, pick.data(), (size_t)ix->nlist * 8, hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) { cleanup(); return fail(MRAG_ERR_HIP, "H2D failed"); }
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ix->nlist + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)x.p,
-                     (const int64_t*)dpick.p, (int64_t)ix->nlist, ix->ld, ix->cen);
+                     (const int64_t*)dpick.p, (int64_t)ix->nlist, ix->ld, ix->cen, 1);
   (void)hipStreamSynchronize(stream);
   for (int it = 0; it < iters; ++it) {
     st = ivf_assign_rows(ix, (const uint16_t*)x.p, n, (int64_t*)ids.p, (float*)sc.p, stream);
@@ -506,7 +507,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     MRAG_TRY(ix->qg.ensure((size_t)n_wg * 256 * ix->ld * 2));
     const int64_t ng = (int64_t)n_wg * 256;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)ix->qbuf.p,
-                       (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p);
+                       (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p, 0);
     MRAG_HIP(hipGetLastError());
   }
   {
