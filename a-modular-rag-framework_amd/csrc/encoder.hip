@@ -594,17 +594,23 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __re
       }
     }
   }
-  // out[row][hh*DH + 16*d + (lane&15)], row = qb*64 + w*16 + (lane>>4)*4 + r
+  // out[row][hh*DH + 16*d + (lane&15)], row = qb*64 + w*16 + (lane>>4)*4 + r.  The wave's 16 x DH block goes
+  // through its (now idle) P slab so that it leaves as 16-byte pieces of whole DH-wide rows instead of
+  // sixteen 2-byte stores per lane.
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = qb * 64 + w * 16 + (lane >> 4) * 4 + r;
-    if (row >= S) continue;
     const float inv = 1.0f / l_run[r];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
-      const elem v = (elem)(o[d][r] * inv);
-      __builtin_memcpy(&out[((size_t)bb * S + row) * H + hh * DH + d * 16 + (lane & 15)], &v, 2);
-    }
+    for (int d = 0; d < ND; ++d) sP[w][(lane >> 4) * 4 + r][d * 16 + (lane & 15)] = (elem)(o[d][r] * inv);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  constexpr int PIECES = DH / 8;                 // 16-byte pieces per row
+  for (int e = lane; e < 16 * PIECES; e += 64) {
+    const int rr = e / PIECES, pc = e % PIECES;
+    const int row = qb * 64 + w * 16 + rr;
+    if (row < S) *(frag*)&out[((size_t)bb * S + row) * H + hh * DH + pc * 8] = *(const frag*)&sP[w][rr][pc * 8];
   }
 }
 
