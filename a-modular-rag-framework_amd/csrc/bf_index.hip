@@ -1375,28 +1375,24 @@ static int grow_rows(BfIndex* ix, int64_t need_rows, hipStream_t stream) {
 
 // choose the corpus split count for T query tiles
 static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
-  if (n_ctiles < 8) { *S_out = std::max(1, n_ctiles); *xcd_out = 0; return; }
-  if (n_ctiles < 64) {
-    // small corpus (e.g. the IVF centroid table): every workgroup pays a first-tile bootstrap and an
-    // end-of-split compaction, so one wave of workgroups with several tiles each beats 2-3 waves of
-    // one-tile workgroups (10 k queries x 4096 centroids, k = 32: K2 0.75 -> 0.3 ms, K4 merges 6 lists not 16)
-    *S_out = std::max(1, std::min(n_ctiles, 256 / std::max(1, T)));
-    *xcd_out = 0;
-    return;
-  }
-  static int qg = 0, smul = 0;
-  if (!qg) {   // tuning knobs (defaults chosen from measurements)
+  // ONE wave of workgroups: S = floor(CUs / T) corpus splits per query tile (T <= 64 per launch).  Every
+  // workgroup pays a first-tile bootstrap, loose thresholds in its early tiles and an end-of-split
+  // compaction (~4.4 tiles' worth, measured), so few long splits beat the 2.5-5 waves of shorter ones a
+  // CU-multiple grid needs -- even with T*S a little short of the CU count: 10 k queries (T = 40, S = 6,
+  // 240 of 256 CUs) against S = 32: 2.43 -> 2.02 ms at 125 k rows, 4.22 -> 3.79 at 250 k, 7.60 -> 7.27 at
+  // 500 k, 14.41 -> 14.32 at 1M.  (With S % 8 != 0 the XCD-aware block map is off; it never moved the time.)
+  static int qg = 0, n_cu = 0;
+  if (!qg) {   // tuning / experiment knobs
     const char* e = getenv("MRAG_QG"); qg = e ? atoi(e) : 8; if (qg != 4 && qg != 8 && qg != 2 && qg != 16) qg = 8;
-    const char* m = getenv("MRAG_SMUL"); smul = m ? atoi(m) : 1; if (smul < 1) smul = 1;
+    hipDeviceProp_t pr; int dev = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+               ? pr.multiProcessorCount : 256;
   }
-  int g = T, b = 256;
-  while (b) { int r = g % b; g = b; b = r; }   // gcd(T, 256)
-  int S = 256 / g;
-  if (S < 8) S = 8;
-  S *= smul;
-  if (S > n_ctiles) S = (n_ctiles / 8) * 8;
+  int S = std::max(1, std::min(n_ctiles, n_cu / std::max(1, T)));
+  { const char* fs = getenv("MRAG_S");   // experiment: force the split count
+    if (fs && atoi(fs) > 0) S = std::min(atoi(fs), n_ctiles); }
   *S_out = S;
-  *xcd_out = qg;
+  *xcd_out = (S % 8 == 0 && n_ctiles >= 64) ? qg : 0;
 }
 
 
