@@ -466,23 +466,13 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     int t, s;
     const int b = blockIdx.x;
     if (p.xcd_map) {
-      const int QG = p.xcd_map;                       // query tiles that run together on one XCD
-      const int x = b & 7, idx = b >> 3, sx = p.S >> 3;
-      const int full = (p.T / QG) * sx * QG;
-      int g, j, tl;
-      if (idx < full) {
-        g = idx / (sx * QG);
-        const int rem = idx - g * (sx * QG);
-        j = rem / QG;
-        tl = rem - j * QG;
-      } else {
-        const int sz = p.T % QG, r2 = idx - full;
-        g = p.T / QG;
-        j = r2 / sz;
-        tl = r2 - j * sz;
-      }
-      t = g * QG + tl;
-      s = x + 8 * j;
+      // XCD-aware: blocks go to XCDs round-robin (b & 7); give each XCD a CONTIGUOUS run of the tile-major
+      // (t, s) order: an XCD then works on grid/8/S query tiles (5 at T = 40: 1.9 MB of queries, L2-resident
+      // across corpus tiles) against all S corpus streams, each shared by those query tiles' workgroups
+      const int per = (int)gridDim.x >> 3;
+      const int lin = (b & 7) * per + (b >> 3);
+      t = lin / p.S;
+      s = lin - t * p.S;
     } else {
       s = b % p.S;
       t = b / p.S;
@@ -1380,10 +1370,9 @@ static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
   // compaction (~4.4 tiles' worth, measured), so few long splits beat the 2.5-5 waves of shorter ones a
   // CU-multiple grid needs -- even with T*S a little short of the CU count: 10 k queries (T = 40, S = 6,
   // 240 of 256 CUs) against S = 32: 2.43 -> 2.02 ms at 125 k rows, 4.22 -> 3.79 at 250 k, 7.60 -> 7.27 at
-  // 500 k, 14.41 -> 14.32 at 1M.  (With S % 8 != 0 the XCD-aware block map is off; it never moved the time.)
-  static int qg = 0, n_cu = 0;
-  if (!qg) {   // tuning / experiment knobs
-    const char* e = getenv("MRAG_QG"); qg = e ? atoi(e) : 8; if (qg != 4 && qg != 8 && qg != 2 && qg != 16) qg = 8;
+  // 500 k, 14.41 -> 14.32 at 1M.
+  static int n_cu = 0;
+  if (!n_cu) {
     hipDeviceProp_t pr; int dev = 0;
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
                ? pr.multiProcessorCount : 256;
@@ -1392,7 +1381,7 @@ static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
   { const char* fs = getenv("MRAG_S");   // experiment: force the split count
     if (fs && atoi(fs) > 0) S = std::min(atoi(fs), n_ctiles); }
   *S_out = S;
-  *xcd_out = (S % 8 == 0 && n_ctiles >= 64) ? qg : 0;
+  *xcd_out = ((T * S) % 8 == 0 && n_ctiles >= 64) ? 1 : 0;   // the XCD-aware block map needs a grid that splits evenly over the 8 XCDs
 }
 
 
