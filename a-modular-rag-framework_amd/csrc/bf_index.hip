@@ -21,9 +21,10 @@
 //   is applied to the per-lane SOURCE address (LDS-DMA writes lane-linear).
 //   A workgroup = (query tile t, corpus split s): it walks the tiles of its split with the
 //   running per-query candidate lists (global memory, L2 resident) and thresholds (LDS).
-//   Block -> (t, s) keeps the 8 query tiles x 4 splits that run together on one XCD
-//   (32 CUs) sharing: 8 query tiles stay in that XCD's L2 (3 MiB at d=768), every corpus
-//   tile is fetched from HBM once per 8 query tiles.
+//   One wave of workgroups: S = floor(CUs / T) splits per query tile (T <= 64 per launch); blocks go
+//   to XCDs round-robin, so XCD x gets a contiguous run of the tile-major (t, s) order -- at T = 40
+//   five query tiles (1.9 MiB, L2-resident across corpus tiles) x all six corpus streams, each
+//   shared by those tiles' workgroups.
 //
 // Top-k filter (exact)
 //   Per query a threshold thr certified by ">= k EARLIER rows score >= thr"; a score is listed
