@@ -138,8 +138,16 @@ class ShardedDenseIndex:
 
     def search(self, queries, k: int, nthreads: int = 0, merge: str = "auto", force_collective: bool = False,
                **kw) -> Tuple[np.ndarray, np.ndarray]:
-        sc, ids = self._local_search(queries, k, **kw)
         import torch
+        if self.index is not None and torch.is_tensor(queries) and queries.is_cuda and "out" not in kw:
+            # reuse the device result tensors across calls (they are consumed by the exchange below)
+            key = (int(queries.shape[0]), int(k), queries.device)
+            if self._bufs.get("okey") != key:
+                self._bufs["okey"] = key
+                self._bufs["osc"] = torch.empty((key[0], key[1]), dtype=torch.float32, device=queries.device)
+                self._bufs["oid"] = torch.empty((key[0], key[1]), dtype=torch.int64, device=queries.device)
+            kw = dict(kw, out=(self._bufs["osc"], self._bufs["oid"]))
+        sc, ids = self._local_search(queries, k, **kw)
         if not torch.is_tensor(sc):
             sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
         return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
