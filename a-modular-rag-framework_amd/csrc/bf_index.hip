@@ -519,36 +519,27 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   // asm two at a time.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt
   // below.  M0 (LDS destination base) is written inside the statement that uses it and restored after.
   f32x4 dbg_sink0 = {0.f, 0.f, 0.f, 0.f}, dbg_sink1 = {0.f, 0.f, 0.f, 0.f};   // diag 16384 only
+  auto stage_part = [&](const char* a, const char* b, int buf, int part) {   // part 0,1: corpus chunks; 2,3: query chunks
+    const int op = part >> 1, i = (part & 1) * 2;
+    if (op == 1 && (CPW * w + i) * 8 >= nq_local && DESC) return;
+    const char* base = op ? b : a;
+    const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
+    const char* c0 = base + (size_t)i * chunk_b;
+    const char* c1 = c0 + chunk_b;
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
+        : "memory", "scc");
+  };
   auto stage = [&](const char* a, const char* b, int buf) {
+    static_assert(CPW == 4, "stage_part covers 4 chunks per operand and wave");
 #pragma unroll
-    for (int op = 0; op < 2; ++op) {
-      const char* base = op ? b : a;
-#pragma unroll
-      for (int i = 0; i < CPW; i += 2) {
-        // query rows past the tile's valid queries are never loaded (their thresholds are +inf, whatever the
-        // stale LDS bytes score): an IVF group averages ~80 of 256 queries, the last tile of a batch fewer
-        if (DESC && op == 1 && (CPW * w + i) * 8 >= nq_local) continue;
-        const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
-        const char* c0 = base + (size_t)i * chunk_b;
-        const char* c1 = c0 + chunk_b;
-        if (MRAG_DBG(16384) && (op == 1 || MRAG_DBG(32768))) {
-          // diag 16384: the same bytes by plain 16-byte loads into registers instead of LDS-DMA (loads-only
-          // timing: which side caps the 11.9 TB/s -- the request path or the LDS write side?); + 32768: both operands
-          dbg_sink0 += *(const f32x4*)(c0 + voff_e);   // compiler-visible loads: hipcc keeps the registers and counts the waits
-          dbg_sink1 += *(const f32x4*)(c1 + voff_o);
-          continue;
-        }
-        uint32_t keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
-            : "memory", "scc");
-      }
-    }
+    for (int part = 0; part < 4; ++part) stage_part(a, b, buf, part);
   };
 
   // ---- fragment read offsets ------------------------------------------------------------
@@ -586,10 +577,19 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   frag f1a[8], f1b[NF];
   auto kstep = [&](auto pending_tag) {
     constexpr bool PENDING = decltype(pending_tag)::value;
-    if (pf_left > 0 && !MRAG_DBG(4)) {   // diag 4: ablate the loads
-      stage(a_tile + pf_kk * (BK * 2), q_ptr + pf_kk * (BK * 2), buf ^ 1);
+    // The corpus half of the next stage (the part that can miss L2) goes out at the top of the step; in a
+    // PENDING step the query half (L2-resident) follows between the pending MFMAs, so that the wave feeds the
+    // MFMA pipe again after 4 DMA issues instead of 8.
+    const bool do_stage = pf_left > 0 && !MRAG_DBG(4);   // diag 4: ablate the loads
+    const char* st_a = a_tile + pf_kk * (BK * 2);
+    const char* st_b = q_ptr + pf_kk * (BK * 2);
+    const int st_buf = buf ^ 1;
+    if (do_stage) {
       --pf_left;
       if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+      stage_part(st_a, st_b, st_buf, 0);
+      stage_part(st_a, st_b, st_buf, 1);
+      if (!PENDING || MRAG_DBG(8)) { stage_part(st_a, st_b, st_buf, 2); stage_part(st_a, st_b, st_buf, 3); }
     }
     const char* sb = smem + buf * STAGE_BYTES;
     buf ^= 1;
@@ -610,9 +610,17 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (PENDING) {
 #pragma unroll
-        for (int mf = 0; mf < 8; ++mf)
+        for (int part = 0; part < 4; ++part) {
 #pragma unroll
-          for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+          for (int mf = 2 * part; mf < 2 * part + 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
+          if (part < 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_stage) stage_part(st_a, st_b, st_buf, 2 + part);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
