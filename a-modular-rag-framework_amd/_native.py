@@ -56,8 +56,10 @@ SIGNATURES = {
     "mrag_index_size": [_h, C.POINTER(_i64)],
     "mrag_index_dim": [_h, C.POINTER(_i)],
     "mrag_index_set_id_base": [_h, _i64],
+    "mrag_index_max_k": [_i64, C.POINTER(_i)],
     "mrag_index_get_rows": [_h, _i64, _i64, _vp, _i, _vp],
     "mrag_index_search": [_h, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "mrag_index_score_rows": [_h, _vp, _i, _i, _vp, _i64, _vp, _vp],
     "mrag_index_last_timing": [_h, _fp, _fp],
     "mrag_topk_merge": [_vp, _vp, _i, _i64, _i, _vp, _vp, _i],
     "mrag_topk_merge_device": [_i, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp],

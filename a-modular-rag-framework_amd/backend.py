@@ -56,8 +56,14 @@ def _vectors(ret):
 class HipDenseReranker:
     """``DenseReranker`` with the cosine loop on the GPU.  Same constructor fields."""
 
-    def __init__(self, router, max_pool: int = 200, embed_batch: int = 50, device: int = 0):
+    def __init__(self, router, max_pool: int = 200, embed_batch: int = 50, device: int = 0, corpus=None):
+        """``corpus`` (optional): a :class:`DenseRetrievalBackend` over the docs.jsonl the candidates come
+        from.  Candidates whose id is a row of its index are then scored by row id against the stored
+        embedding -- no embed call for them (the reference pays 1 + ceil(N/bs) embedding
+        round-trips per question, retrieval_backend.py:227-243); candidates it does not know, or whose
+        text differs from the stored row's, are embedded as before."""
         self.router, self.max_pool, self.embed_batch, self.device = router, max_pool, embed_batch, device
+        self.corpus = corpus
 
     def _resolve_embed_model(self) -> str:
         return resolve_embed_model(self.router)
@@ -93,18 +99,47 @@ class HipDenseReranker:
         except Exception as e:                      # :229-231
             logger.error("[HipDenseReranker] query embed error: %s", e)
             return {}
+        known: Dict[int, float] = {}                # candidate position -> score from the stored row
+        if self.corpus is not None:
+            known = self._lookup(ids, texts, qv, model_hint, trace_id)
+        todo = [i for i in range(len(texts)) if i not in known]
         vecs: List[Any] = []
         step = max(8, int(self.embed_batch))        # :234
-        for lo in range(0, len(texts), step):
-            chunk = texts[lo:lo + step]
+        for lo in range(0, len(todo), step):
+            chunk = [texts[i] for i in todo[lo:lo + step]]
             try:
                 got = _vectors(self.router.embed(model_hint=model_hint, texts=chunk, require={"trace_id": trace_id}))
                 vecs.extend(got or [])
             except Exception as e:                  # :241-243
                 logger.error("[HipDenseReranker] batch embed error: %s", e)
                 vecs.extend([[0.0] * len(qv) for _ in chunk])
-        n = min(len(ids), len(vecs))                # zip() truncation of :245
-        return dict(zip(ids[:n], self._cosines(qv, vecs[:n])))
+        n = min(len(todo), len(vecs))               # zip() truncation of :245
+        scored = dict(zip(todo[:n], self._cosines(qv, vecs[:n])))
+        scored.update(known)
+        return {ids[i]: scored[i] for i in range(len(ids)) if i in scored}
+
+    def _lookup(self, ids: List[str], texts: List[str], qv, model_hint: str, trace_id: str) -> Dict[int, float]:
+        """Scores of the candidates that are rows of ``self.corpus``'s index (same embedding model, same
+        text), by row id on the GPU.  Any failure degrades to "nothing known" -- the embed path then
+        scores everything, as the reference does."""
+        try:
+            state = self.corpus._get_state(model_hint, trace_id)
+            ix, row_of, rows = state["index"], state["row_of"], state["rows"]
+            if ix is None or len(qv) != state["dim"]:
+                return {}
+            pos, rid = [], []
+            for i, (hid, text) in enumerate(zip(ids, texts)):
+                r = row_of.get(hid)
+                if r is not None and (rows[r].get("text") or "") == text:
+                    pos.append(i)
+                    rid.append(r)
+            if not pos:
+                return {}
+            sc = ix.score_rows(np.asarray(qv, dtype=np.float32), np.asarray(rid, dtype=np.int64))
+            return {i: float(v) for i, v in zip(pos, sc)}
+        except Exception as e:
+            logger.error("[HipDenseReranker] row lookup failed, embedding every candidate: %s", e)
+            return {}
 
 
 class DenseRetrievalBackend:
@@ -125,50 +160,96 @@ class DenseRetrievalBackend:
         self._state = None
 
     # -- corpus index: built once per (file signature, model), shared process-wide --------------
-    def _embed_texts(self, texts: List[str], model_hint: str, trace_id: str) -> np.ndarray:
+    def _embed_texts(self, texts: List[str], model_hint: str, trace_id: str, dim: Optional[int] = None) -> np.ndarray:
+        """Embed through the router, one call per ``embed_batch`` texts, and VALIDATE every batch.  The
+        router answers ``[[0.0]*3]*n`` instead of raising when the provider fails (llm_router.py:119-129):
+        such a batch (wrong row count, a dim that differs from the first batch / ``dim``, or all zeros)
+        must never be built into -- or cached as -- the corpus index, so it raises here."""
         out = []
         for lo in range(0, len(texts), self.embed_batch):
-            got = _vectors(self.router.embed(model_hint=model_hint, texts=texts[lo:lo + self.embed_batch],
-                                             require={"trace_id": trace_id}))
-            out.append(np.asarray(got, dtype=np.float32))
-        return np.concatenate(out, axis=0) if out else np.zeros((0, 0), dtype=np.float32)
+            chunk = texts[lo:lo + self.embed_batch]
+            got = np.asarray(_vectors(self.router.embed(model_hint=model_hint, texts=chunk,
+                                                        require={"trace_id": trace_id})), dtype=np.float32)
+            if got.ndim != 2 or got.shape[0] != len(chunk):
+                raise ValueError(f"embed batch at row {lo}: expected {len(chunk)} vectors, got shape {got.shape}")
+            if dim is None:
+                dim = int(got.shape[1])
+            if got.shape[1] != dim or dim == 0:
+                raise ValueError(f"embed batch at row {lo}: dim {got.shape[1]}, expected {dim}")
+            if not np.isfinite(got).all():
+                raise ValueError(f"embed batch at row {lo}: non-finite values")
+            if not got.any():
+                raise ValueError(f"embed batch at row {lo}: all-zero vectors (the router's failure fallback)")
+            out.append(got)
+        return np.concatenate(out, axis=0) if out else np.zeros((0, dim or 0), dtype=np.float32)
 
     def _build_state(self, model_hint: str, trace_id: str):
         from .index import DenseIndex
         rows = _corpus.read_docs_jsonl(self.index_path)
-        state = {"rows": rows, "index": None, "dim": 0}
+        state = {"rows": rows, "index": None, "dim": 0, "row_of": {}}
         if not rows:
             return state
-        emb, cache, key = None, None, None
-        if self.cache_dir:
-            cache = _corpus.EmbeddingCache(self.cache_dir)
         texts = [r.get("text") or "" for r in rows]
+        probe = self._embed_texts(texts[:1], model_hint, trace_id)
+        dim = int(probe.shape[1])
+        cache = _corpus.EmbeddingCache(self.cache_dir) if self.cache_dir else None
+        bits, key = None, None
         if cache is not None:
-            probe = self._embed_texts(texts[:1], model_hint, trace_id)
-            key = cache.key(self.index_path, model_hint, probe.shape[1], self.index_dtype)
-            emb = cache.load(key)
-            if emb is not None and emb.shape != (len(rows), probe.shape[1]):
-                emb = None
-        if emb is None:
-            emb = self._embed_texts(texts, model_hint, trace_id)
-            if cache is not None:
-                cache.store(key, emb.astype(np.float16), {"model": model_hint, "rows": len(rows), "dim": int(emb.shape[1]),
-                                                          "docs": _corpus.file_signature(self.index_path)})
-        ix = DenseIndex(int(emb.shape[1]), metric="cosine", dtype=self.index_dtype, device=self.device)
+            key = cache.key(self.index_path, model_hint, dim, self.index_dtype)
+            bits = cache.load(key)
+            if bits is not None and (bits.shape != (len(rows), dim) or bits.dtype != np.uint16):
+                bits = None
+        ix = DenseIndex(dim, metric="cosine", dtype=self.index_dtype, device=self.device)
         step = 131072
-        for lo in range(0, len(rows), step):
-            ix.add(np.ascontiguousarray(emb[lo:lo + step]))
-        state["index"], state["dim"] = ix, int(emb.shape[1])
+        if bits is not None:
+            # warm start: the cache holds the 16-bit patterns K1 produced in the cold build; they are
+            # re-added verbatim, so cold and warm indexes are bit-identical (doc-id order near ties
+            # cannot depend on the cache state)
+            for lo in range(0, len(rows), step):
+                ix.add_stored_bits(np.ascontiguousarray(bits[lo:lo + step]))
+        else:
+            emb = self._embed_texts(texts, model_hint, trace_id, dim=dim)
+            for lo in range(0, len(rows), step):
+                ix.add(np.ascontiguousarray(emb[lo:lo + step]))       # K1: fp64 norm, ONE rounding
+            if cache is not None:
+                cache.store(key, ix.stored_bits(), {"model": model_hint, "rows": len(rows), "dim": dim,
+                                                    "dtype": self.index_dtype, "format": "storage bits (uint16)",
+                                                    "docs": _corpus.file_signature(self.index_path)})
+        state["index"], state["dim"] = ix, dim
+        # raw hit id (retrieval_backend.py:116-119) -> corpus row, for the re-ranker's lookup by id; ids that
+        # occur twice (duplicate doc_id lines) are ambiguous and left out: such candidates are embedded as before
+        seen: Dict[str, int] = {}
+        for r in rows:
+            hid = _fusion.raw_hit_id(r)
+            seen[hid] = seen.get(hid, 0) + 1
+        row_of: Dict[str, int] = {}
+        for i, r in enumerate(rows):
+            hid = _fusion.raw_hit_id(r)
+            if seen[hid] == 1:
+                row_of[hid] = i
+        state["row_of"] = row_of
         return state
+
+    _FAIL_BACKOFF_S = 30.0
+    _failed: Dict[str, Any] = {}        # key -> (monotonic deadline, error text): no re-embed storm after a failed build
 
     def _get_state(self, model_hint: str, trace_id: str):
         if self._state is None:
+            import time
             try:
                 sig = _corpus.file_signature(self.index_path)
             except OSError:
                 sig = f"{self.index_path}|missing"
             key = f"dense-index|{sig}|{model_hint}|{self.device}|{self.index_dtype}"
-            self._state = _corpus.shared(key, lambda: self._build_state(model_hint, trace_id))
+            bad = DenseRetrievalBackend._failed.get(key)
+            if bad and time.monotonic() < bad[0]:
+                raise RuntimeError(f"corpus index build failed {self._FAIL_BACKOFF_S:.0f}s ago or less: {bad[1]}")
+            try:
+                self._state = _corpus.shared(key, lambda: self._build_state(model_hint, trace_id))
+            except Exception as e:
+                DenseRetrievalBackend._failed[key] = (time.monotonic() + self._FAIL_BACKOFF_S, repr(e))
+                raise
+            DenseRetrievalBackend._failed.pop(key, None)
         return self._state
 
     # -- the backend protocol ---------------------------------------------------------------------
@@ -190,6 +271,7 @@ class DenseRetrievalBackend:
 
         dense_hits: List[Dict[str, Any]] = []
         dense_error = None
+        k_eff = 0
         with span("Backend/DenseRerank", self.sink, trace_id):      # same span name as :332
             try:
                 state = self._get_state(model_hint, trace_id)
@@ -198,8 +280,11 @@ class DenseRetrievalBackend:
                                                                require={"trace_id": trace_id}))[0], dtype=np.float32)
                     if qv.shape[0] != state["dim"]:
                         raise ValueError(f"query embedding has dim {qv.shape[0]}, corpus has {state['dim']}")
-                    k = min(pool, len(state["rows"]), 64)
-                    sc, ids = state["index"].search(qv[None, :], k)
+                    # the reference scores its whole pool (retrieval_backend.py:218,245); the index serves
+                    # k up to max_k() (256) -- anything beyond is reported, never silently dropped
+                    k = min(pool, len(state["rows"]))
+                    k_eff = min(k, state["index"].max_k(1))
+                    sc, ids = state["index"].search(qv[None, :], k_eff)
                     for s, i in zip(sc[0], ids[0]):
                         if i < 0:
                             continue
@@ -227,7 +312,7 @@ class DenseRetrievalBackend:
             "graph_candidates": len(g_hits),
             "dense_scored": len(dense_scores),
             "weights": {"alpha_text": self.alpha_text, "alpha_graph": self.alpha_graph, "alpha_dense": self.alpha_dense},
-            "pool": {"dense_pool_k": self.dense_pool_k, "final_top_k": top_k},
+            "pool": {"dense_pool_k": self.dense_pool_k, "final_top_k": top_k, "dense_pool_k_effective": k_eff},
             "resolved_embed_model": model_hint,
             "dense_backend": "mrag_amd.DenseIndex",
             "dense_error": dense_error,

@@ -48,7 +48,9 @@ def file_signature(path) -> str:
 
 
 class EmbeddingCache:
-    """fp16 embedding matrix of a docs.jsonl under ``cache_dir`` as ``<key>.npy`` + ``<key>.json``."""
+    """Embedding matrix of a docs.jsonl under ``cache_dir`` as ``<key>.npy`` + ``<key>.json``: the 16-bit
+    patterns (uint16) of the index's storage dtype exactly as K1 produced them, so that an index rebuilt
+    from the cache is bit-identical to the one first built from the encoder's output."""
 
     def __init__(self, cache_dir):
         self.dir = Path(cache_dir)
@@ -70,25 +72,61 @@ class EmbeddingCache:
         (self.dir / f"{key}.json").write_text(json.dumps(info))
 
 
-_REGISTRY: Dict[str, Any] = {}
-_LOCK = threading.Lock()
+class _Slot:
+    """One registry entry: the value once built, and the event its builder sets."""
+    __slots__ = ("done", "value", "error", "owner")
+
+    def __init__(self):
+        self.done = threading.Event()
+        self.value: Any = None
+        self.error: Optional[BaseException] = None
+        self.owner = threading.get_ident()
+
+
+_REGISTRY: Dict[str, _Slot] = {}
+_LOCK = threading.Lock()          # guards the dict only; never held while a build() runs
 
 
 def shared(key: str, build: Callable[[], Any]):
-    """Process-wide singleton: ``build()`` runs once per key (SURVEY 8b "Threading")."""
+    """Process-wide singleton: ``build()`` runs once per key (SURVEY 8b "Threading").
+
+    ``build()`` runs OUTSIDE the registry lock, so a builder may itself call ``shared`` for
+    another key (the corpus index builder reaches the provider's encoder through the router);
+    other callers of the SAME key wait for the builder.  A failed build is not cached: the
+    error propagates to everyone waiting and the next caller builds again."""
     with _LOCK:
-        if key not in _REGISTRY:
-            _REGISTRY[key] = build()
-        return _REGISTRY[key]
+        slot = _REGISTRY.get(key)
+        mine = slot is None
+        if mine:
+            slot = _REGISTRY[key] = _Slot()
+    if mine:
+        try:
+            slot.value = build()
+        except BaseException as e:
+            slot.error = e
+            with _LOCK:
+                if _REGISTRY.get(key) is slot:
+                    del _REGISTRY[key]
+            raise
+        finally:
+            slot.done.set()
+        return slot.value
+    if not slot.done.is_set() and slot.owner == threading.get_ident():
+        raise RuntimeError(f"shared({key!r}): build() re-entered its own key")
+    slot.done.wait()
+    if slot.error is not None:
+        raise slot.error
+    return slot.value
 
 
 def drop_shared(prefix: str = "") -> None:
     with _LOCK:
-        for k in [k for k in _REGISTRY if k.startswith(prefix)]:
-            obj = _REGISTRY.pop(k)
-            close = getattr(obj, "close", None)
-            if callable(close):
-                try:
-                    close()
-                except Exception:
-                    pass
+        slots = [_REGISTRY.pop(k) for k in [k for k in _REGISTRY if k.startswith(prefix)]]
+    for slot in slots:
+        slot.done.wait()
+        close = getattr(slot.value, "close", None)
+        if callable(close):
+            try:
+                close()
+            except Exception:
+                pass

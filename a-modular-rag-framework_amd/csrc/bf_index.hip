@@ -1022,16 +1022,22 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 // k-th best to a 128-entry LDS list, 64 rows at a time, and compacts the list (rank by counting)
 // when it passes 64.  Algorithmic bytes per launch = N*D*2 (+ 16*D*2).
 // ------------------------------------------------------------------------------------------
-constexpr int SQ = 16;                               // queries per block
+constexpr int SQ = 16;                               // query columns per block (one MFMA B fragment)
 constexpr int S_NST = 3;
 constexpr int S_STAGE = A_BYTES + SQ * BK * 2;       // 32 KiB corpus + 2 KiB queries
 constexpr int S_OFF_SC = S_NST * S_STAGE;            // float [16][260] score tile
 constexpr int S_SC_LD = 260;
-constexpr int S_OFF_LIST = S_OFF_SC + SQ * S_SC_LD * 4;   // uint2 [16][128]
-constexpr int S_LCAP = 128;
-constexpr int S_OFF_CNT = S_OFF_LIST + SQ * S_LCAP * 8;   // int [16]
-constexpr int S_OFF_TAU = S_OFF_CNT + 64;                 // float [16]
-constexpr int S_LDS_TOTAL = S_OFF_TAU + 64;
+constexpr int S_OFF_LIST = S_OFF_SC + SQ * S_SC_LD * 4;   // uint2 [queries][LCAP]
+// Two instances: QPW = 2 queries per wave (16 per block) with 128-entry lists serves k <= 64;
+// QPW = 1 (8 per block) with 512-entry lists serves k <= KMAX_WIDE = 256 -- the reference's dense pool
+// is 200 candidates per question (config/settings.yaml:101-102, retrieval_backend.py:218).
+constexpr int KMAX_WIDE = 256;
+template <int QPW, int LCAP> struct StreamLds {
+  static constexpr int NQB = 8 * QPW;                                  // queries per block
+  static constexpr int OFF_CNT = S_OFF_LIST + NQB * LCAP * 8;          // int [16]
+  static constexpr int OFF_TAU = OFF_CNT + 64;                         // float [16]
+  static constexpr int TOTAL = OFF_TAU + 64;
+};
 
 struct StreamParams {
   const uint16_t* corpus;
@@ -1041,27 +1047,29 @@ struct StreamParams {
   int* counts;               // [wg*256 + q]
 };
 
-// one wave: cut query q's LDS list to its k best (sorted), raise tau
+// one wave: cut query q's LDS list (<= 64*R entries) to its k best (sorted), raise tau
+template <int R>
 __device__ __forceinline__ void stream_compact(uint2* __restrict__ lst, int* __restrict__ cnt, float* __restrict__ tau, int q, int k, int lane) {
   const int c = cnt[q];
-  uint2 e[2];
-  uint64_t key[2];
-  int rank[2] = {0, 0};
+  uint2 e[R];
+  uint64_t key[R];
+  int rank[R];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < R; ++r) {
     const int i = r * 64 + lane;
     e[r] = i < c ? lst[i] : make_uint2(0u, 0u);
     key[r] = i < c ? make_key(e[r].x, e[r].y) : 0ull;
+    rank[r] = 0;
   }
   for (int j = 0; j < c; ++j) {
     const uint2 o = lst[j];                       // broadcast read
     const uint64_t kj = make_key(o.x, o.y);
-    rank[0] += kj > key[0] ? 1 : 0;
-    rank[1] += kj > key[1] ? 1 : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) rank[r] += kj > key[r] ? 1 : 0;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < R; ++r) {
     const int i = r * 64 + lane;
     if (i < c && rank[r] < k) {
       lst[rank[r]] = e[r];
@@ -1071,9 +1079,11 @@ __device__ __forceinline__ void stream_compact(uint2* __restrict__ lst, int* __r
   if (lane == 0) cnt[q] = min(c, k);
 }
 
-template <int DT>
+template <int DT, int QPW, int LCAP>
 __global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p) {
   typedef typename Mfma<DT>::frag frag;
+  typedef StreamLds<QPW, LCAP> L;
+  static_assert(LCAP % 64 == 0 && LCAP >= 128, "list capacity: whole 64-entry appends + compaction head room");
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x;
@@ -1082,8 +1092,8 @@ __global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p)
   const int ksteps = p.ksteps, n_tiles = tile_hi - tile_lo;
   float* sc = (float*)(smem + S_OFF_SC);
   uint2* lists = (uint2*)(smem + S_OFF_LIST);
-  int* cnt = (int*)(smem + S_OFF_CNT);
-  float* tau = (float*)(smem + S_OFF_TAU);
+  int* cnt = (int*)(smem + L::OFF_CNT);
+  float* tau = (float*)(smem + L::OFF_TAU);
   if (tid < SQ) { cnt[tid] = 0; tau[tid] = -INFINITY; }
 
   const uint32_t row_b = (uint32_t)p.ld * 2u;
@@ -1166,10 +1176,10 @@ __global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p)
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 #pragma unroll 1
-    for (int qq = 0; qq < 2; ++qq) {
-      const int qi = 2 * w + qq;
+    for (int qq = 0; qq < QPW; ++qq) {
+      const int qi = QPW * w + qq;
       if (qi >= p.nq) continue;
-      uint2* lst = lists + qi * S_LCAP;
+      uint2* lst = lists + qi * LCAP;
 #pragma unroll 1
       for (int c0 = 0; c0 < TM; c0 += 64) {
         const float v = sc[qi * S_SC_LD + c0 + lane];
@@ -1181,18 +1191,18 @@ __global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p)
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) cnt[qi] = base + __popcll(bal);
           __builtin_amdgcn_wave_barrier();
-          if (base + __popcll(bal) > S_LCAP - 64) stream_compact(lst, cnt, tau, qi, p.k, lane);
+          if (base + __popcll(bal) > LCAP - 64) stream_compact<LCAP / 64>(lst, cnt, tau, qi, p.k, lane);
         }
       }
     }
     __syncthreads();   // score tile free again
   }
   // ---- end of the split: k best per query (sorted) into the K4 layout ------------------------
-  for (int qq = 0; qq < 2; ++qq) {
-    const int qi = 2 * w + qq;
+  for (int qq = 0; qq < QPW; ++qq) {
+    const int qi = QPW * w + qq;
     if (qi >= p.nq) { if (lane == 0 && qi < SQ) p.counts[(size_t)wg * TQ + qi] = 0; continue; }
-    uint2* lst = lists + qi * S_LCAP;
-    stream_compact(lst, cnt, tau, qi, p.k, lane);
+    uint2* lst = lists + qi * LCAP;
+    stream_compact<LCAP / 64>(lst, cnt, tau, qi, p.k, lane);
     __builtin_amdgcn_wave_barrier();
     const int c = cnt[qi];
     uint2* out = p.list + ((size_t)wg * TQ + qi) * QCAP;
@@ -1315,6 +1325,88 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   }
 }
 
+// K4w (64 < k <= 256, the online regime with the reference's 200-candidate pool): one 256-thread workgroup
+// per query selects the k best of the S regions' sorted lists straight from global memory (S*k <= 65 536
+// keys, L2-resident): MSB-first radix select of the k-th key (8 bits per pass over an LDS histogram, stops
+// as soon as the bucket holding the k-th key is needed whole), the k selected keys gathered into LDS and
+// ranked by counting.  Same order as K4: (score desc, row asc); slots past the corpus are (-inf, -1).
+__global__ __launch_bounds__(256) void bf_merge_wide_kernel(MergeParams p) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint64_t sel[KMAX_WIDE];
+  __shared__ int cnts[256];
+  __shared__ int s_pick[3];     // digit, keys above it, keys in its bin
+  __shared__ int s_nsel;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t q = blockIdx.x;
+  if (q >= p.nq) return;
+  const int t = (int)(q / TQ), ql = (int)(q % TQ);
+  const int k = p.k, S = p.S;
+  cnts[tid] = tid < S ? min(p.counts[(size_t)(t * S + tid) * TQ + ql], k) : 0;
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  int total = 0;
+  for (int r = 0; r < S; ++r) total += cnts[r];
+  const int span = S * k;       // entry idx -> (region idx / k, slot idx % k)
+  auto fetch = [&](int idx, uint64_t& key) -> bool {
+    const int r = idx / k, i = idx - r * k;
+    if (i >= cnts[r]) return false;
+    const uint2 e = p.list[((size_t)(t * S + r) * TQ + ql) * QCAP + i];
+    key = make_key(e.x, e.y);
+    return true;
+  };
+  int shift = 0;
+  uint64_t prefix = 0ull;
+  if (total > k) {
+    int need = k;
+    for (shift = 56; shift >= 0; shift -= 8) {
+      hist[tid] = 0u;
+      __syncthreads();
+      for (int idx = tid; idx < span; idx += 256) {
+        uint64_t key;
+        if (fetch(idx, key) && (shift == 56 || (key >> (shift + 8)) == prefix))
+          atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {           // wave 0: bins 4*lane .. 4*lane+3, suffix sums over the lanes above
+        const int hb[4] = {(int)hist[lane * 4], (int)hist[lane * 4 + 1], (int)hist[lane * 4 + 2], (int)hist[lane * 4 + 3]};
+        const int mine = hb[0] + hb[1] + hb[2] + hb[3];
+        int suf = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_down(suf, off);
+          if (lane + off < 64) suf += v;
+        }
+        int cum = suf - mine;
+#pragma unroll
+        for (int b = 3; b >= 0; --b) {
+          if (cum < need && cum + hb[b] >= need) { s_pick[0] = lane * 4 + b; s_pick[1] = cum; s_pick[2] = hb[b]; }
+          cum += hb[b];
+        }
+      }
+      __syncthreads();
+      const int digit = s_pick[0], above = s_pick[1], inb = s_pick[2];
+      need -= above;
+      prefix = (prefix << 8) | (uint64_t)digit;
+      if (inb == need) break;   // the whole bucket is selected
+    }
+    if (shift < 0) shift = 0;
+  }
+  for (int idx = tid; idx < span; idx += 256) {
+    uint64_t key;
+    if (fetch(idx, key) && (key >> shift) >= prefix) sel[atomicAdd(&s_nsel, 1)] = key;
+  }
+  __syncthreads();
+  const int nsel = s_nsel;      // = min(total, k): keys are unique (the row is in the key)
+  if (tid < nsel) {
+    const uint64_t my = sel[tid];
+    int rank = 0;
+    for (int j = 0; j < nsel; ++j) rank += sel[j] > my ? 1 : 0;
+    p.out_scores[q * k + rank] = ord_f32((uint32_t)(my >> 32));
+    p.out_ids[q * k + rank] = p.id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)my);
+  }
+  for (int i = nsel + tid; i < k; i += 256) { p.out_scores[q * k + i] = -INFINITY; p.out_ids[q * k + i] = -1; }
+}
+
 __global__ void fill_empty_kernel(float* sc, int64_t* ids, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { sc[i] = -INFINITY; ids[i] = -1; }
@@ -1331,6 +1423,28 @@ __global__ void unpack_rows_kernel(const uint16_t* __restrict__ src, int ld, int
   if (is_bf16) f = __uint_as_float((uint32_t)b << 16);
   else { _Float16 h; __builtin_memcpy(&h, &b, 2); f = (float)h; }
   out[i] = f;
+}
+
+// one wave per listed row: score = <prepared query, stored row> (fp64 accumulation of the exact 16-bit products)
+__global__ __launch_bounds__(256) void score_rows_kernel(const uint16_t* __restrict__ rows, const uint16_t* __restrict__ q, int ld,
+                                                         int is_bf16, const int64_t* __restrict__ ids, int64_t n, int64_t n_rows,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t r = ids[i];
+  if (r < 0 || r >= n_rows) { if (lane == 0) out[i] = 0.0f; return; }   // unknown row: the reference's 0.0 for an unusable vector
+  const uint16_t* row = rows + (size_t)r * ld;
+  double acc = 0.0;
+  for (int c = lane; c < ld; c += 64) {
+    float a, b;
+    if (is_bf16) { a = __uint_as_float((uint32_t)row[c] << 16); b = __uint_as_float((uint32_t)q[c] << 16); }
+    else { _Float16 ha, hb; __builtin_memcpy(&ha, &row[c], 2); __builtin_memcpy(&hb, &q[c], 2); a = (float)ha; b = (float)hb; }
+    acc += (double)a * (double)b;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) out[i] = (float)acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1396,7 +1510,8 @@ static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
 }
 
 
-int bf_max_k() { return KMAX; }
+int bf_max_k() { return KMAX; }            // fused batch kernel / IVF list scan
+int bf_max_k_wide() { return KMAX_WIDE; }  // streaming kernel, 8 queries per launch
 int64_t bf_round_rows(int64_t n) { return round_up(n, TM); }
 
 // Query batches are cut so that one launch keeps its candidate lists (4.6 KB per workgroup and
@@ -1423,7 +1538,7 @@ static int launch_k2(int dtype, size_t grid, hipStream_t stream, const BfParams&
 }
 
 int bf_launch(const BfLaunch& a) {
-  if (a.k <= 0 || a.k > KMAX) return fail(MRAG_ERR_UNSUPPORTED, "k = %d outside 1..%d", a.k, KMAX);
+  if (a.k <= 0 || a.k > (a.wg_desc ? KMAX : KMAX_WIDE)) return fail(MRAG_ERR_UNSUPPORTED, "k = %d outside 1..%d", a.k, a.wg_desc ? KMAX : KMAX_WIDE);
   hipStream_t stream = a.stream;
   const int di = a.dtype == MRAG_F16 ? 0 : 1;
   BfParams p;
@@ -1468,32 +1583,42 @@ int bf_launch(const BfLaunch& a) {
     return MRAG_OK;
   }
   const int n_ctiles = (int)((a.n_rows + TM - 1) / TM);
-  if (a.nq <= SQ && n_ctiles >= 8) {
+  if (a.k > KMAX || (a.nq <= SQ && n_ctiles >= 8)) {
     // ---- online regime: HBM-bound streaming kernel (K2s), one workgroup per CU-sized corpus split ----
-    static bool s_attr[2] = {false, false};
-    if (!s_attr[di]) {
-      if (di == 0) MRAG_HIP(hipFuncSetAttribute((const void*)bf_stream_topk_kernel<MRAG_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
-      else MRAG_HIP(hipFuncSetAttribute((const void*)bf_stream_topk_kernel<MRAG_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_TOTAL));
-      s_attr[di] = true;
+    // k <= 64: up to 16 queries per launch; 64 < k <= 256: 8 per launch with 512-entry lists, any nq
+    // (larger batches run as consecutive 8-query launches: exact, HBM-bound per launch, not the batch kernel)
+    typedef void (*SFn)(StreamParams);
+    static const SFn sfns[2][2] = {{bf_stream_topk_kernel<MRAG_F16, 2, 128>, bf_stream_topk_kernel<MRAG_F16, 1, 512>},
+                                   {bf_stream_topk_kernel<MRAG_BF16, 2, 128>, bf_stream_topk_kernel<MRAG_BF16, 1, 512>}};
+    static const int slds[2] = {StreamLds<2, 128>::TOTAL, StreamLds<1, 512>::TOTAL};
+    static bool s_attr[2][2] = {};
+    const int wi = a.k > KMAX ? 1 : 0;
+    const int grp = wi ? 8 : SQ;
+    if (!s_attr[di][wi]) {
+      MRAG_HIP(hipFuncSetAttribute((const void*)sfns[di][wi], hipFuncAttributeMaxDynamicSharedMemorySize, slds[wi]));
+      s_attr[di][wi] = true;
     }
-    const int S = std::min(n_ctiles, 256);
+    const int S = std::max(1, std::min(n_ctiles, 256));
     MRAG_TRY(a.lists->ensure((size_t)S * TQ * QCAP * 8));
     MRAG_TRY(a.counts->ensure((size_t)S * TQ * sizeof(int)));
-    StreamParams sp;
-    sp.corpus = a.corpus; sp.queries = a.queries; sp.ld = a.ld; sp.ksteps = a.ld / BK;
-    sp.n_rows = (int)a.n_rows; sp.n_ctiles = n_ctiles; sp.nq = (int)a.nq; sp.S = S; sp.k = a.k;
-    sp.list = (uint2*)a.lists->p; sp.counts = (int*)a.counts->p;
-    if (di == 0) hipLaunchKernelGGL((bf_stream_topk_kernel<MRAG_F16>), dim3((unsigned)S), dim3(NTHR), S_LDS_TOTAL, stream, sp);
-    else hipLaunchKernelGGL((bf_stream_topk_kernel<MRAG_BF16>), dim3((unsigned)S), dim3(NTHR), S_LDS_TOTAL, stream, sp);
-    MRAG_HIP(hipGetLastError());
-    if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
-    MergeParams mp;
-    mp.list = sp.list; mp.counts = sp.counts;
-    mp.T = 1; mp.S = S; mp.k = a.k; mp.nq = a.nq; mp.id_base = a.id_base;
-    mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
-    mp.out_scores = a.out_scores; mp.out_ids = a.out_ids;
-    hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)a.nq), dim3(64), 0, stream, mp);
-    MRAG_HIP(hipGetLastError());
+    for (int64_t g0 = 0; g0 < a.nq; g0 += grp) {
+      const int64_t gq = std::min<int64_t>(grp, a.nq - g0);
+      StreamParams sp;
+      sp.corpus = a.corpus; sp.queries = a.queries + (size_t)g0 * a.ld; sp.ld = a.ld; sp.ksteps = a.ld / BK;
+      sp.n_rows = (int)a.n_rows; sp.n_ctiles = n_ctiles; sp.nq = (int)gq; sp.S = S; sp.k = a.k;
+      sp.list = (uint2*)a.lists->p; sp.counts = (int*)a.counts->p;
+      hipLaunchKernelGGL(sfns[di][wi], dim3((unsigned)S), dim3(NTHR), slds[wi], stream, sp);
+      MRAG_HIP(hipGetLastError());
+      if (g0 + grp >= a.nq && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+      MergeParams mp;
+      mp.list = sp.list; mp.counts = sp.counts;
+      mp.T = 1; mp.S = S; mp.k = a.k; mp.nq = gq; mp.id_base = a.id_base;
+      mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
+      mp.out_scores = a.out_scores + (size_t)g0 * a.k; mp.out_ids = a.out_ids + (size_t)g0 * a.k;
+      if (wi) hipLaunchKernelGGL(bf_merge_wide_kernel, dim3((unsigned)gq), dim3(256), 0, stream, mp);
+      else hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)gq), dim3(64), 0, stream, mp);
+      MRAG_HIP(hipGetLastError());
+    }
     return MRAG_OK;
   }
   // ---- dense mode: (query tile, corpus split) grid, query batches of <= 64 tiles ----------------
@@ -1588,7 +1713,11 @@ int mrag_index_reserve(mrag_handle h, int64_t n_rows) {
   if (!ix) return MRAG_ERR_INVALID;
   if (n_rows < 0 || n_rows > 0x7FFFFF00ll) return fail(MRAG_ERR_INVALID, "n_rows out of range");
   MRAG_TRY(use_device(ix->device));
-  return grow_rows(ix, n_rows, nullptr);
+  MRAG_TRY(grow_rows(ix, n_rows, nullptr));
+  // the zero fill / copy above ran on the null stream; callers add and search on their own (non-blocking)
+  // streams, which are not ordered behind it: finish it here (reserve is a one-off)
+  MRAG_HIP(hipStreamSynchronize(nullptr));
+  return MRAG_OK;
 }
 
 int mrag_index_add(mrag_handle h, const void* rows, int64_t n, int src_dtype, int normalize, int rows_is_device,
@@ -1641,6 +1770,13 @@ int mrag_index_set_id_base(mrag_handle h, int64_t id_base) {
   return MRAG_OK;
 }
 
+int mrag_index_max_k(int64_t nq, int* out_k) {
+  if (!out_k) return fail(MRAG_ERR_INVALID, "out_k is NULL");
+  (void)nq;   // every batch size is served up to the wide limit (k > 64 runs 8 queries per launch)
+  *out_k = KMAX_WIDE;
+  return MRAG_OK;
+}
+
 int mrag_index_get_rows(mrag_handle h, int64_t row0, int64_t n, float* out, int out_is_device, void* stream_) {
   BfIndex* ix = (BfIndex*)lookup(h, KIND_BF_INDEX);
   if (!ix) return MRAG_ERR_INVALID;
@@ -1670,7 +1806,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
   if (!ix) return MRAG_ERR_INVALID;
   if (nq < 0) return fail(MRAG_ERR_INVALID, "nq < 0");
   if (k <= 0) return fail(MRAG_ERR_INVALID, "k must be positive");
-  if (k > KMAX) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the fused top-k limit %d", k, KMAX);
+  if (k > KMAX_WIDE) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the top-k limit %d (see mrag_index_max_k)", k, KMAX_WIDE);
   if (nq == 0) return MRAG_OK;
   if (!queries || !out_scores || !out_ids) return fail(MRAG_ERR_INVALID, "NULL buffer");
   const size_t esz = dtype_size(q_dtype);
@@ -1697,7 +1833,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     MRAG_HIP(hipEventRecord(ix->ev[2], stream));
   } else {
     // queries -> storage dtype, zero padded to a multiple of 256 rows
-    const int64_t nq_pad = round_up(nq, TQ);
+    const int64_t nq_pad = round_up(nq, TQ) + SQ;   // + 16 zero rows: the last 8-query group of the k > 64 path reads a 16-row block
     const size_t qbytes = (size_t)nq_pad * ix->ld * 2;
     MRAG_TRY(ix->qbuf.ensure(qbytes));
     const void* qsrc = queries;
@@ -1707,8 +1843,7 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       MRAG_HIP(hipMemcpyAsync(ix->stage_in.p, queries, bytes, hipMemcpyHostToDevice, stream));
       qsrc = ix->stage_in.p;
     }
-    if (nq_pad > nq)
-      MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
+    MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
     MRAG_TRY(launch_prep_rows(qsrc, q_dtype, nq, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                               normalize && ix->metric == MRAG_METRIC_COSINE, stream));
     BfLaunch a;
@@ -1730,6 +1865,34 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipStreamSynchronize(stream));
   }
+  return MRAG_OK;
+}
+
+int mrag_index_score_rows(mrag_handle h, const void* query, int q_dtype, int normalize, const int64_t* row_ids, int64_t n,
+                          float* out_scores, void* stream_) {
+  BfIndex* ix = (BfIndex*)lookup(h, KIND_BF_INDEX);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (n < 0) return fail(MRAG_ERR_INVALID, "n < 0");
+  if (n == 0) return MRAG_OK;
+  if (!query || !row_ids || !out_scores) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  const size_t esz = dtype_size(q_dtype);
+  if (!esz) return fail(MRAG_ERR_INVALID, "unknown query dtype %d", q_dtype);
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  // staging: [query src | row ids | scores]; prepared query in qbuf (one row)
+  const size_t qb = round_up((int64_t)(ix->dim * esz), 256), ib = round_up(n * 8, 256), ob = (size_t)n * 4;
+  MRAG_TRY(ix->stage_in.ensure(qb + ib + ob));
+  MRAG_TRY(ix->qbuf.ensure((size_t)(TQ + SQ) * ix->ld * 2));
+  char* st = (char*)ix->stage_in.p;
+  MRAG_HIP(hipMemcpyAsync(st, query, (size_t)ix->dim * esz, hipMemcpyHostToDevice, stream));
+  MRAG_HIP(hipMemcpyAsync(st + qb, row_ids, (size_t)n * 8, hipMemcpyHostToDevice, stream));
+  MRAG_TRY(launch_prep_rows(st, q_dtype, 1, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
+                            normalize && ix->metric == MRAG_METRIC_COSINE, stream));
+  hipLaunchKernelGGL(score_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, ix->rows, (const uint16_t*)ix->qbuf.p,
+                     ix->ld, ix->dtype == MRAG_BF16 ? 1 : 0, (const int64_t*)(st + qb), n, ix->n, (float*)(st + qb + ib));
+  MRAG_HIP(hipGetLastError());
+  MRAG_HIP(hipMemcpyAsync(out_scores, st + qb + ib, ob, hipMemcpyDeviceToHost, stream));
+  MRAG_HIP(hipStreamSynchronize(stream));
   return MRAG_OK;
 }
 

@@ -88,6 +88,7 @@ struct BfLaunch {
 };
 int bf_launch(const BfLaunch& a);
 int bf_max_k();
+int bf_max_k_wide();
 int64_t bf_round_rows(int64_t n);     // rows rounded up to the kernel's tile (256)
 
 }  // namespace mrag

@@ -136,6 +136,44 @@ class DenseIndex:
                                             sc.ctypes.data, ids.ctypes.data, 0, _stream_ptr(stream)))
         return sc, ids
 
+    def max_k(self, nq: int = 1) -> int:
+        """Largest ``k`` :meth:`search` serves (``mrag_index_max_k``); above it the library raises
+        MRAG_ERR_UNSUPPORTED, it never clamps."""
+        out = C.c_int(0)
+        N.check(self._lib.mrag_index_max_k(int(nq), C.byref(out)))
+        return out.value
+
+    def score_rows(self, query, row_ids, normalize: Optional[bool] = None) -> np.ndarray:
+        """<query, stored row i> for every listed row (``mrag_index_score_rows``): the re-ranker's
+        candidate lookup by row id.  Ids outside the index score 0.0."""
+        if normalize is None:
+            normalize = self.metric == "cosine"
+        q = np.ascontiguousarray(np.asarray(query, dtype=np.float32).reshape(-1))
+        if q.shape[0] != self.dim:
+            raise ValueError(f"query has dim {q.shape[0]}, index has {self.dim}")
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64).reshape(-1)
+        out = np.empty(ids.shape[0], dtype=np.float32)
+        N.check(self._lib.mrag_index_score_rows(self._h, q.ctypes.data, N.MRAG_F32, int(bool(normalize)), ids.ctypes.data,
+                                                ids.shape[0], out.ctypes.data, None))
+        return out
+
+    def stored_bits(self) -> np.ndarray:
+        """The stored rows as their 16-bit patterns ([n, dim] uint16, fp16 or bf16 per ``dtype``):
+        what the embedding cache keeps, so that a warm start re-adds the exact bits K1 produced."""
+        r = self.rows()
+        if self.dtype == "f16":
+            return r.astype(np.float16).view(np.uint16)       # exact: every stored value is an fp16 value
+        return (r.view(np.uint32) >> 16).astype(np.uint16)     # exact: low 16 bits of a widened bf16 are zero
+
+    def add_stored_bits(self, bits: np.ndarray):
+        """Append rows given as the storage dtype's bit patterns, verbatim (no normalise, no rounding)."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint16)
+        if self.dtype == "f16":
+            self.add(bits.view(np.float16), normalize=False)
+        else:
+            import torch
+            self.add(torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16), normalize=False)
+
     def last_timing_ms(self) -> Tuple[float, float]:
         """(fused similarity+top-k kernel ms, whole search ms) of the last search, from
         hipEvents recorded on the launch stream."""

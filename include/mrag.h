@@ -86,11 +86,22 @@ int mrag_index_dim(mrag_handle h, int* out_dim);
 int mrag_index_set_id_base(mrag_handle h, int64_t id_base);
 /* copy stored (rounded) rows [row0, row0+n) back as fp32 [n, dim] -- for tests/caches */
 int mrag_index_get_rows(mrag_handle h, int64_t row0, int64_t n, float* out, int out_is_device, void* stream);
+/* largest k mrag_index_search serves for a batch of nq queries (256: the reference's dense pool is 200
+ * candidates per question, config/settings.yaml:101-102 / retrieval_backend.py:218,276).  k <= 64 runs
+ * the fused batch kernel; 64 < k <= 256 runs the streaming kernel 8 queries per launch (exact, HBM-bound). */
+int mrag_index_max_k(int64_t nq, int* out_k);
 /* top-k of every query against every stored row.  out_scores [nq,k] fp32 descending,
- * out_ids [nq,k] int64; slots past the corpus size hold (-inf, -1). */
+ * out_ids [nq,k] int64; slots past the corpus size hold (-inf, -1).  k > mrag_index_max_k:
+ * MRAG_ERR_UNSUPPORTED (never a silent clamp). */
 int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize,
                       int queries_is_device, int k, float* out_scores, int64_t* out_ids,
                       int out_is_device, void* stream);
+/* the re-ranker's candidate lookup by row id.  Replaces the 1 + ceil(N/bs) embed calls +
+ * N x _cosine of DenseReranker.score (retrieval_backend.py:227-245) for candidates whose rows are already
+ * in the index: out_scores[i] = <query, stored row row_ids[i]> (the cosine when rows and query are
+ * normalised); an id outside [0, size) scores 0.0 like an unusable vector (:193-197).  Host buffers. */
+int mrag_index_score_rows(mrag_handle h, const void* query, int q_dtype, int normalize, const int64_t* row_ids,
+                          int64_t n, float* out_scores, void* stream);
 /* timing hooks for bench.py: device time in ms of the dominant kernel (fused similarity
  * GEMM + top-k) and of the whole search of the LAST mrag_index_search call, measured with
  * hipEvents on the stream the kernels were launched on.  Blocks until that call is done. */

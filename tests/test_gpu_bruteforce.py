@@ -208,7 +208,7 @@ def test_errors_are_loud():
     from mrag_amd._native import MragError
     ix = DenseIndex(32)
     with pytest.raises(MragError):
-        ix.search(np.zeros((1, 32), np.float32), 65)      # k above the fused limit
+        ix.search(np.zeros((1, 32), np.float32), 257)     # k above mrag_index_max_k (256)
     with pytest.raises(ValueError):
         ix.add(np.zeros((3, 31), np.float32))
     sc, ids = ix.search(np.ones((2, 32), np.float32), 3)   # empty index
