@@ -61,6 +61,8 @@ SIGNATURES = {
     "mrag_index_search": [_h, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mrag_index_score_rows": [_h, _vp, _i, _i, _vp, _i64, _vp, _vp],
     "mrag_index_last_timing": [_h, _fp, _fp],
+    "mrag_index_measure_clock": [_h, _i],
+    "mrag_index_last_clock": [_h, _fp],
     "mrag_topk_merge": [_vp, _vp, _i, _i64, _i, _vp, _vp, _i],
     "mrag_topk_merge_device": [_i, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp],
     "mrag_ivf_create": [_i, _i, _i, _i, _i, C.POINTER(_h)],
@@ -73,11 +75,13 @@ SIGNATURES = {
     "mrag_ivf_set_id_base": [_h, _i64],
     "mrag_ivf_get_assignments": [_h, _vp, _i, _vp],
     "mrag_ivf_search": [_h, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "mrag_ivf_last_timing": [_h, _fp, _fp, C.POINTER(_i64), C.POINTER(_i)],
     "mrag_encoder_create": [C.POINTER(EncoderConfig), _i, C.POINTER(_h)],
     "mrag_encoder_destroy": [_h],
     "mrag_encoder_set_param": [_h, C.c_char_p, _vp, _i64, _i, _vp],
     "mrag_encoder_missing_params": [_h, C.POINTER(_i)],
     "mrag_encoder_forward": [_h, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "mrag_encoder_last_timing": [_h, _fp],
 }
 
 

@@ -85,6 +85,7 @@ struct BfLaunch {
   DevBuf* counts = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev_k2_begin = nullptr, ev_k2_end = nullptr;   // optional
+  long long* clock = nullptr;         // optional device long long[4]: batch kernel workgroup 0's clock stamps
 };
 int bf_launch(const BfLaunch& a);
 int bf_max_k();

@@ -668,7 +668,10 @@ struct Encoder : Object {
   std::map<std::string, bool> have;
   std::vector<void*> allocs;
   DevBuf ids, mask, x, y, qkv, ctx, ffn, out, stage;
+  hipEvent_t ev[2] = {nullptr, nullptr};   // device work of the last forward (embeddings .. pooling), on its stream
+  bool timed = false;
   ~Encoder() override {
+    for (auto& v : ev) if (v) (void)hipEventDestroy(v);
     for (void* p : allocs) (void)hipFree(p);
     for (DevBuf* b : {&ids, &mask, &x, &y, &qkv, &ctx, &ffn, &out, &stage}) b->release();
   }
@@ -941,12 +944,29 @@ int mrag_encoder_forward(mrag_handle h, const int32_t* ids, const int32_t* mask,
   MRAG_HIP(hipMemcpyAsync(e->mask.p, mask, nb, kin, stream));
   float* d_out = out;
   if (!io_is_device) { MRAG_TRY(e->out.ensure((size_t)B * e->cfg.hidden * 4)); d_out = (float*)e->out.p; }
+  e->timed = false;
+  for (auto& v : e->ev)
+    if (!v) MRAG_HIP(hipEventCreate(&v));
+  MRAG_HIP(hipEventRecord(e->ev[0], stream));
   if (e->cfg.compute_dtype == MRAG_F16) MRAG_TRY(forward_impl<MRAG_F16>(e, B, S, d_out, pool, normalize, stream));
   else MRAG_TRY(forward_impl<MRAG_BF16>(e, B, S, d_out, pool, normalize, stream));
+  MRAG_HIP(hipEventRecord(e->ev[1], stream));
+  e->timed = true;
   if (!io_is_device) {
     MRAG_HIP(hipMemcpyAsync(out, d_out, (size_t)B * e->cfg.hidden * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipStreamSynchronize(stream));
   }
+  return MRAG_OK;
+}
+
+int mrag_encoder_last_timing(mrag_handle h, float* out_ms) {
+  Encoder* e = (Encoder*)lookup(h, KIND_ENCODER);
+  if (!e) return MRAG_ERR_INVALID;
+  if (!e->timed) return fail(MRAG_ERR_INVALID, "no completed forward to time");
+  if (!out_ms) return fail(MRAG_ERR_INVALID, "out_ms is NULL");
+  MRAG_TRY(use_device(e->device));
+  MRAG_HIP(hipEventSynchronize(e->ev[1]));
+  MRAG_HIP(hipEventElapsedTime(out_ms, e->ev[0], e->ev[1]));
   return MRAG_OK;
 }
 

@@ -12,7 +12,8 @@
 //               rows are streamed from HBM ONCE for all of them (HBM-bound: bytes = list rows x
 //               ld x 2 per workgroup), scored on MFMA and filtered by the same in-kernel top-k
 //            3) per query the nprobe candidate sets are merged by (score desc, original row asc)
-//   The (list -> queries) regrouping of step 2 runs on the host from the D2H'd probe table.
+//   The (list -> queries) regrouping of step 2 runs on the device (count / plan / scatter kernels below);
+//   only the workgroup count comes back to the host.
 #include "common.h"
 
 #include <algorithm>
@@ -35,7 +36,11 @@ struct IvfIndex : Object {
   std::vector<int> list_tile_lo, list_count;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | list scan begin | list scan end | search end
+  bool timed = false;
+  int last_n_wg = 0;
   ~IvfIndex() override {
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
     for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan}) b->release();
   }
@@ -127,6 +132,12 @@ __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t n
   const int wgi = wg_first[l] + (pos >> 8), slot = pos & 255;
   gq[(size_t)wgi * 256 + slot] = i / nprobe;
   ploc[i] = make_int2(wgi, slot);
+}
+
+// nprobe == nlist: every query probes every list (the exhaustive limit, == brute force)
+__global__ void ivf_all_lists_kernel(int64_t* __restrict__ probes, int64_t npairs, int nlist) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npairs) probes[i] = i % nlist;
 }
 
 __global__ void ids_to_i32_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ out) {
@@ -269,6 +280,8 @@ int mrag_ivf_create(int dim, int nlist, int metric, int storage_dtype, int devic
   const size_t cb = (size_t)bf_round_rows(nlist) * ix->ld * 2;
   if (hipMalloc((void**)&ix->cen, cb) != hipSuccess) { delete ix; return fail(MRAG_ERR_OOM, "centroid allocation failed"); }
   (void)hipMemset(ix->cen, 0, cb);
+  for (auto& e : ix->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete ix; return fail(MRAG_ERR_HIP, "hipEventCreate failed"); }
   *out = register_object(ix);
   return MRAG_OK;
 }
@@ -443,7 +456,10 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   if (nq < 0 || k <= 0 || nprobe <= 0) return fail(MRAG_ERR_INVALID, "bad nq / k / nprobe");
   if (k > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the fused top-k limit %d", k, bf_max_k());
   nprobe = std::min(nprobe, ix->nlist);
-  if (nprobe > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "nprobe = %d exceeds %d", nprobe, bf_max_k());
+  // probe selection = top-nprobe over the centroids: the fused kernel up to 64, the streaming kernel up to 256
+  // (8 queries per launch); nprobe == nlist needs no selection at all
+  if (nprobe > bf_max_k_wide() && nprobe < ix->nlist)
+    return fail(MRAG_ERR_UNSUPPORTED, "nprobe = %d: supported are 1..%d and nlist (= %d, exhaustive)", nprobe, bf_max_k_wide(), ix->nlist);
   if (nq == 0) return MRAG_OK;
   if (!queries || !out_scores || !out_ids || !esize(q_dtype)) return fail(MRAG_ERR_INVALID, "bad buffer / dtype");
   if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "index has no centroids");
@@ -451,6 +467,8 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   MRAG_TRY(use_device(ix->device));
   hipStream_t stream = (hipStream_t)stream_;
   MRAG_TRY(ivf_finalize(ix, stream));
+  ix->timed = false;
+  MRAG_HIP(hipEventRecord(ix->ev[0], stream));
 
   float* d_sc = out_scores;
   int64_t* d_id = out_ids;
@@ -461,13 +479,17 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     d_id = (int64_t*)ix->out_id.p;
   }
   // 1) queries -> storage dtype; probe lists
-  const int64_t nq_pad = bf_round_rows(nq);
+  const int64_t nq_pad = bf_round_rows(nq) + 16;   // + 16 zero rows: the streaming kernel's last 8-query group reads a 16-row block
   MRAG_TRY(ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2));
   MRAG_HIP(hipMemsetAsync(ix->qbuf.p, 0, (size_t)nq_pad * ix->ld * 2, stream));
   MRAG_TRY(ivf_prepare(ix, queries, nq, q_dtype, normalize, queries_is_device, (uint16_t*)ix->qbuf.p, stream));
   MRAG_TRY(ix->tmp_id.ensure((size_t)nq * nprobe * 8));
   MRAG_TRY(ix->tmp_sc.ensure((size_t)nq * nprobe * 4));
-  {
+  if (nprobe == ix->nlist) {
+    const int64_t np_ = nq * nprobe;
+    hipLaunchKernelGGL(ivf_all_lists_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, stream, (int64_t*)ix->tmp_id.p, np_, ix->nlist);
+    MRAG_HIP(hipGetLastError());
+  } else {
     BfLaunch a;
     a.corpus = ix->cen; a.queries = (const uint16_t*)ix->qbuf.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = nprobe;
     a.nq = nq; a.n_rows = ix->nlist;
@@ -520,13 +542,40 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     a.id_base = ix->id_base;
     a.out_scores = d_sc; a.out_ids = d_id;
     a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
+    a.ev_k2_begin = ix->ev[1]; a.ev_k2_end = ix->ev[2];
     MRAG_TRY(bf_launch(a));
   }
+  MRAG_HIP(hipEventRecord(ix->ev[3], stream));
+  ix->last_n_wg = n_wg;
+  ix->timed = true;
   if (!out_is_device) {
     MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
   }
   MRAG_HIP(hipStreamSynchronize(stream));   // host vectors above must outlive the async copies
+  return MRAG_OK;
+}
+
+int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms, int64_t* out_scanned_rows, int* out_n_wg) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (!ix->timed) return fail(MRAG_ERR_INVALID, "no completed search to time");
+  MRAG_TRY(use_device(ix->device));
+  MRAG_HIP(hipEventSynchronize(ix->ev[3]));
+  float g = 0.f, t = 0.f;
+  MRAG_HIP(hipEventElapsedTime(&g, ix->ev[1], ix->ev[2]));
+  MRAG_HIP(hipEventElapsedTime(&t, ix->ev[0], ix->ev[3]));
+  if (out_scan_ms) *out_scan_ms = g;
+  if (out_total_ms) *out_total_ms = t;
+  if (out_n_wg) *out_n_wg = ix->last_n_wg;
+  if (out_scanned_rows) {
+    // rows streamed by the list scan = sum over its workgroups of their list's length (descriptor words 2, 4)
+    std::vector<int> d((size_t)ix->last_n_wg * 8);
+    if (ix->last_n_wg) MRAG_HIP(hipMemcpy(d.data(), ix->desc.p, d.size() * 4, hipMemcpyDeviceToHost));
+    int64_t rows = 0;
+    for (int w = 0; w < ix->last_n_wg; ++w) rows += (int64_t)d[(size_t)w * 8 + 4] - (int64_t)d[(size_t)w * 8 + 2] * 256;
+    *out_scanned_rows = rows;
+  }
   return MRAG_OK;
 }
 

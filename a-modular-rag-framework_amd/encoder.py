@@ -47,41 +47,31 @@ class EncoderSpec:
                     type_vocab_size=self.type_vocab_size, layer_norm_eps=self.layer_norm_eps, pool=self.pool)
 
 
+def param_shapes(spec: EncoderSpec) -> Dict[str, tuple]:
+    """HF ``BertModel`` state-dict names (no pooler) -> shapes, in state-dict order."""
+    H, I = spec.hidden, spec.intermediate
+    shapes: Dict[str, tuple] = {"embeddings.word_embeddings.weight": (spec.vocab_size, H),
+                                "embeddings.position_embeddings.weight": (spec.max_position, H),
+                                "embeddings.token_type_embeddings.weight": (spec.type_vocab_size, H),
+                                "embeddings.LayerNorm.weight": (H,), "embeddings.LayerNorm.bias": (H,)}
+    for i in range(spec.layers):
+        p = f"encoder.layer.{i}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            shapes[p + n + ".weight"], shapes[p + n + ".bias"] = (H, H), (H,)
+        shapes[p + "intermediate.dense.weight"], shapes[p + "intermediate.dense.bias"] = (I, H), (I,)
+        shapes[p + "output.dense.weight"], shapes[p + "output.dense.bias"] = (H, I), (H,)
+        for n in ("attention.output.LayerNorm", "output.LayerNorm"):
+            shapes[p + n + ".weight"], shapes[p + n + ".bias"] = (H,), (H,)
+    return shapes
+
+
 def seeded_weights(spec: EncoderSpec, seed: int) -> Dict[str, np.ndarray]:
     """Deterministic fp32 parameters (N(0,0.05) matrices, 0.02 N(0,1) biases, LayerNorm gains
-    1 + 0.1 N(0,1)), drawn in HF state-dict order from ``default_rng(seed)``."""
-    H, I = spec.hidden, spec.intermediate
-    names = [("embeddings.word_embeddings.weight", (spec.vocab_size, H)),
-             ("embeddings.position_embeddings.weight", (spec.max_position, H)),
-             ("embeddings.token_type_embeddings.weight", (spec.type_vocab_size, H)),
-             ("embeddings.LayerNorm.weight", (H,)), ("embeddings.LayerNorm.bias", (H,))]
-    for i in range(spec.layers):
-        p = f"encoder.layer.{i}."
-        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-            names += [(p + n + ".weight", (H, H)), (p + n + ".bias", (H,))]
-        names += [(p + "intermediate.dense.weight", (I, H)), (p + "intermediate.dense.bias", (I,)),
-                  (p + "output.dense.weight", (H, I)), (p + "output.dense.bias", (H,))]
-        for n in ("attention.output.LayerNorm", "output.LayerNorm"):
-            names += [(p + n + ".weight", (H,)), (p + n + ".bias", (H,))]
-    # same draw order as a dict built embeddings -> per layer {q,k,v,o (w,b)}, ffn, LNs
-    order = {}
-    for name, shape in names:
-        order[name] = shape
+    1 + 0.1 N(0,1)), drawn in state-dict order from ``default_rng(seed)`` -- the generator the test
+    fixtures were captured with (tests/golden/f6_encoder.npz stores the SHA-256 of its output)."""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    # NOTE: iteration order must match oracle.encoder.param_shapes (tests compare both generators)
-    H_first = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
-               "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
-    seq = list(H_first)
-    for i in range(spec.layers):
-        p = f"encoder.layer.{i}."
-        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-            seq += [p + n + ".weight", p + n + ".bias"]
-        seq += [p + "intermediate.dense.weight", p + "intermediate.dense.bias", p + "output.dense.weight", p + "output.dense.bias"]
-        for n in ("attention.output.LayerNorm", "output.LayerNorm"):
-            seq += [p + n + ".weight", p + n + ".bias"]
-    for name in seq:
-        shape = order[name]
+    for name, shape in param_shapes(spec).items():
         if name.endswith("LayerNorm.weight"):
             out[name] = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
         elif name.endswith(".bias"):
@@ -197,6 +187,12 @@ class HipSentenceEncoder:
         N.check(self._lib.mrag_encoder_forward(self._h, ids.ctypes.data, mask.ctypes.data, B, S, out.ctypes.data,
                                                N.POOL_CLS if pool == "cls" else N.POOL_MEAN, int(bool(normalize)), 0, None))
         return out
+
+    def last_timing_ms(self) -> float:
+        """Device ms of the last forward's kernels (``mrag_encoder_last_timing``)."""
+        ms = C.c_float(0)
+        N.check(self._lib.mrag_encoder_last_timing(self._h, C.byref(ms)))
+        return ms.value
 
     def tokenize(self, texts: List[str]):
         seqs = [self.tokenizer.encode(t, self.max_length) for t in texts]

@@ -174,6 +174,16 @@ class DenseIndex:
             import torch
             self.add(torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16), normalize=False)
 
+    def measure_clock(self, enable: bool = True):
+        """Ask the batch kernel's workgroup 0 to stamp s_memtime / s_memrealtime (``mrag_index_measure_clock``)."""
+        N.check(self._lib.mrag_index_measure_clock(self._h, int(bool(enable))))
+
+    def last_clock_ghz(self) -> float:
+        """Held shader clock during the last batch-kernel search (``mrag_index_last_clock``)."""
+        g = C.c_float(0)
+        N.check(self._lib.mrag_index_last_clock(self._h, C.byref(g)))
+        return g.value
+
     def last_timing_ms(self) -> Tuple[float, float]:
         """(fused similarity+top-k kernel ms, whole search ms) of the last search, from
         hipEvents recorded on the launch stream."""
@@ -290,8 +300,25 @@ class IVFFlatIndex:
         N.check(self._lib.mrag_ivf_get_assignments(self._h, out.ctypes.data, 0, None))
         return out
 
-    def search(self, queries, k: int, nprobe: int, normalize: Optional[bool] = None) -> Tuple[np.ndarray, np.ndarray]:
+    def last_timing(self) -> dict:
+        """Device timing of the last search: list-scan kernel ms, whole-search ms, rows the scan streamed,
+        workgroups (``mrag_ivf_last_timing``)."""
+        g, t, rows, nwg = C.c_float(0), C.c_float(0), C.c_int64(0), C.c_int(0)
+        N.check(self._lib.mrag_ivf_last_timing(self._h, C.byref(g), C.byref(t), C.byref(rows), C.byref(nwg)))
+        return {"scan_ms": g.value, "total_ms": t.value, "scanned_rows": rows.value, "n_wg": nwg.value}
+
+    def search(self, queries, k: int, nprobe: int, normalize: Optional[bool] = None):
+        """-> (scores [nq,k], ids [nq,k]); host queries give numpy arrays, CUDA tensors give CUDA tensors
+        (the call returns when they are complete).  ``nprobe``: 1..256, or ``nlist`` (exhaustive)."""
         keep, ptr, nq, dt, is_dev = _as_buffer(queries, self.dim)
+        if is_dev:
+            import torch
+            sc = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
+            ids = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
+            stream = torch.cuda.current_stream(self.device)
+            N.check(self._lib.mrag_ivf_search(self._h, ptr, nq, dt, self._norm(normalize), 1, int(nprobe), int(k),
+                                              sc.data_ptr(), ids.data_ptr(), 1, _stream_ptr(stream)))
+            return sc, ids
         sc = np.empty((nq, k), dtype=np.float32)
         ids = np.empty((nq, k), dtype=np.int64)
         N.check(self._lib.mrag_ivf_search(self._h, ptr, nq, dt, self._norm(normalize), is_dev, int(nprobe), int(k),

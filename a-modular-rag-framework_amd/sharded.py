@@ -7,8 +7,13 @@ process group is ``nccl``; ``gloo`` in the CPU tests) followed by the merge: on 
 then the only thing that crosses PCIe (C4 at 8 GPUs: 1.2 MB instead of 9.6 MB + 0.5 ms of host
 merge per step).  Result = the single-GPU result: ids are global, tie-break (score desc, id asc).
 
-The exchange is latency-bound: Q*k*(4+8) bytes per rank (C4: 10 000 x 10 -> 1.2 MB), so a
-direct all-gather on the fully connected xGMI mesh, no ring tuning, no all-reduce.
+The exchange is ONE collective of 8-byte (fp32 score bits, int32 shard-local row) words -- Q*k*8 bytes per
+rank (C4: 10 000 x 10 -> 800 KB, 6.4 MB gathered at 8 GPUs) -- latency-bound, so a direct all-gather on the
+fully connected xGMI mesh, no ring tuning, no all-reduce; global ids are rebuilt from the rank's row base,
+which every rank knows (``shard_bounds``).
+
+``ShardedIVFIndex`` is the same for IVF-flat (BASELINE config 5): rows sharded, centroids trained once and
+replicated, so every GPU holds 1/N of every list and does equal work for any probe set.
 """
 from __future__ import annotations
 
@@ -38,7 +43,7 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, bufs: Optional[dict] = None,
-                     merge: str = "auto", force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+                     merge: str = "auto", force_collective: bool = False, id_bases=None) -> Tuple[np.ndarray, np.ndarray]:
     """All-gather the per-shard partial top-k and merge.  ``merge``: "host" (mrag_topk_merge),
     "device" (mrag_topk_merge_device, CUDA tensors only) or "auto" (device when it applies).
 
@@ -46,7 +51,8 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
     backend's device (CUDA for nccl, CPU for gloo).  Every rank returns the full merged
     (scores [Q,k] float32, ids [Q,k] int64) as numpy arrays.  ``bufs`` (a dict the caller
     keeps) caches the gather / pinned staging buffers across calls; with CUDA inputs the returned
-    arrays are views of pinned buffers that stay valid until the call after the next one."""
+    arrays are views of pinned buffers that stay valid until the call after the next one.
+    ``id_bases``: first global row of every rank's shard (needed when more than one rank takes part)."""
     import torch
     import torch.distributed as dist
 
@@ -67,13 +73,36 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
     if bufs.get("key") != key:
         bufs.clear()
         bufs["key"] = key
-        bufs["gs"] = torch.empty((world, q, k), dtype=torch.float32, device=local_scores.device)
-        bufs["gi"] = torch.empty((world, q, k), dtype=torch.int64, device=local_ids.device)
-    gs, gi = bufs["gs"], bufs["gi"]
-    # output = the inputs concatenated along dim 0 (the layout both nccl and gloo accept)
-    dist.all_gather_into_tensor(gs.view(world * q, k), local_scores.contiguous(), group=group)
-    dist.all_gather_into_tensor(gi.view(world * q, k), local_ids.contiguous(), group=group)
+        bufs["gw"] = torch.empty((world, q, k), dtype=torch.int64, device=local_scores.device)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bases = bufs.get("bases")
+    if bases is None or bases.shape[0] != world:
+        if id_bases is None:
+            raise ValueError("gather_and_merge needs id_bases (first global row of every rank) for N > 1")
+        bases = bufs["bases"] = torch.as_tensor(list(id_bases), dtype=torch.int64, device=local_scores.device).view(world, 1, 1)
+    gw = bufs["gw"]
+    # ONE collective: (score bits << 32) | shard-local row (0xFFFFFFFF = empty slot); output = the inputs
+    # concatenated along dim 0 (the layout both nccl and gloo accept)
+    dist.all_gather_into_tensor(gw.view(world * q, k), pack_partial(local_scores, local_ids, int(bases[rank])), group=group)
+    gs, gi = unpack_partial(gw, bases)
     return merge_gathered(gs, gi, bufs, merge=merge, nthreads=nthreads)
+
+
+def pack_partial(scores, ids, id_base: int):
+    """[Q,k] fp32 scores + int64 GLOBAL ids (-1 = empty) -> int64 words: score bits in the high half, the
+    shard-local row (id - id_base, 32 bits) in the low half."""
+    import torch
+    local = torch.where(ids >= 0, ids - id_base, torch.full_like(ids, 0xFFFFFFFF))
+    return (scores.contiguous().view(torch.int32).to(torch.int64) << 32) | (local & 0xFFFFFFFF)
+
+
+def unpack_partial(words, bases):
+    """Inverse of :func:`pack_partial` for gathered words [world,Q,k]; ``bases`` [world,1,1] int64."""
+    import torch
+    scores = (words >> 32).to(torch.int32).view(torch.float32)
+    low = words & 0xFFFFFFFF
+    ids = torch.where(low == 0xFFFFFFFF, torch.full_like(low, -1), low + bases)
+    return scores, ids
 
 
 def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
@@ -151,4 +180,63 @@ class ShardedDenseIndex:
         if not torch.is_tensor(sc):
             sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
         return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
-                                force_collective=force_collective)
+                                force_collective=force_collective,
+                                id_bases=[shard_bounds(self.n_total, self.world, r)[0] for r in range(self.world)])
+
+
+class ShardedIVFIndex:
+    """One rank's view of a row-sharded IVF-flat index (BASELINE config 5): rank r holds rows
+    ``shard_bounds(n_total, world, r)`` of EVERY list; the centroids are trained once (rank 0) and broadcast,
+    so all ranks probe the same lists and scan equal shares of them; the per-shard top-k meets in the same
+    one-collective exchange + merge as the brute-force index.  Result = the single-GPU IVF result for the
+    same centroids.
+
+    ``local_search(queries, k, nprobe) -> (scores, ids)`` defaults to an :class:`IVFFlatIndex` on this rank's
+    GPU; tests inject a CPU searcher to exercise the exchange on ``gloo``."""
+
+    def __init__(self, dim: int, nlist: int, n_total: int, rank: int, world: int, device: int = 0, group=None,
+                 dtype: str = "f16", metric: str = "cosine", local_search: Optional[Callable] = None):
+        self.dim, self.nlist, self.n_total, self.rank, self.world, self.group = dim, nlist, n_total, rank, world, group
+        self.lo, self.hi = shard_bounds(n_total, world, rank)
+        self._bufs: dict = {}
+        self.index = None
+        if local_search is None:
+            from .index import IVFFlatIndex
+            self.index = IVFFlatIndex(dim, nlist, metric=metric, dtype=dtype, device=device)
+            self.index.set_id_base(self.lo)
+            local_search = self.index.search
+        self._local_search = local_search
+
+    def train(self, sample_rows, iters: int = 10, seed: int = 0, normalize=None):
+        """k-means on rank 0 (``sample_rows`` is ignored elsewhere), centroids broadcast to every rank."""
+        import torch
+        import torch.distributed as dist
+        cen = None
+        if self.rank == 0:
+            self.index.train(sample_rows, iters=iters, seed=seed, normalize=normalize)
+            cen = self.index.centroids()
+        if self.world > 1:
+            dev = torch.device("cuda", self.index.device) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            t = torch.from_numpy(cen).to(dev) if self.rank == 0 else torch.empty((self.nlist, self.dim), dtype=torch.float32, device=dev)
+            dist.broadcast(t, src=0, group=self.group)
+            if self.rank != 0:
+                self.index.set_centroids(t.cpu().numpy(), normalize=False)     # already normalised + rounded
+        return self
+
+    def set_centroids(self, centroids, normalize=None):
+        self.index.set_centroids(centroids, normalize=normalize)
+
+    def add_local(self, rows, normalize=None):
+        self.index.add(rows, normalize=normalize)
+        if len(self.index) > self.hi - self.lo:
+            raise ValueError("more rows than this shard owns")
+
+    def search(self, queries, k: int, nprobe: int, nthreads: int = 0, merge: str = "auto",
+               force_collective: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        import torch
+        sc, ids = self._local_search(queries, k, nprobe)
+        if not torch.is_tensor(sc):
+            sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
+        return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
+                                force_collective=force_collective,
+                                id_bases=[shard_bounds(self.n_total, self.world, r)[0] for r in range(self.world)])

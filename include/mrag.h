@@ -106,6 +106,11 @@ int mrag_index_score_rows(mrag_handle h, const void* query, int q_dtype, int nor
  * GEMM + top-k) and of the whole search of the LAST mrag_index_search call, measured with
  * hipEvents on the stream the kernels were launched on.  Blocks until that call is done. */
 int mrag_index_last_timing(mrag_handle h, float* out_gemm_ms, float* out_total_ms);
+/* held shader clock under the fused kernel (SURVEY 8d "record held clock"): with the reading enabled, workgroup 0
+ * of the batch kernel stamps s_memtime / s_memrealtime at entry and exit; last_clock = d(cycles) / d(100 MHz ticks).
+ * MRAG_ERR_UNSUPPORTED when the last search ran the streaming kernel (no stamps). */
+int mrag_index_measure_clock(mrag_handle h, int enable);
+int mrag_index_last_clock(mrag_handle h, float* out_ghz);
 
 /* ---- 8e: host-side merge of per-shard partial top-k ------------------------------
  * scores [nparts, nq, k] fp32 and ids [nparts, nq, k] int64 (ids < 0 = empty slot), as
@@ -138,6 +143,10 @@ int mrag_ivf_get_assignments(mrag_handle h, int32_t* out, int out_is_device, voi
 int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize,
                     int queries_is_device, int nprobe, int k, float* out_scores, int64_t* out_ids,
                     int out_is_device, void* stream);
+/* measurement hooks for bench.py (like mrag_index_last_timing): device ms of the list-scan kernel and of the
+ * whole LAST mrag_ivf_search (hipEvents on its stream), the rows that scan streamed (sum over its
+ * workgroups of their list's length: x ld x 2 = the algorithmic HBM bytes) and its workgroup count. */
+int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms, int64_t* out_scanned_rows, int* out_n_wg);
 
 /* ---- a5: sentence-encoder forward, fills the LLMProvider.embed slot ---------------
  * app/core/providers/base.py:6, called as embed(model=, texts=, require=) from
@@ -167,6 +176,9 @@ int mrag_encoder_missing_params(mrag_handle h, int* out_missing);
 /* ids/mask int32 [B,S]; out fp32 [B,hidden] */
 int mrag_encoder_forward(mrag_handle h, const int32_t* ids, const int32_t* mask, int B, int S,
                          float* out, int pool, int normalize, int io_is_device, void* stream);
+/* measurement hook for bench.py: device ms of the LAST forward's kernels (embeddings .. pooling), from
+ * hipEvents on its stream; the ids/mask H2D and the output D2H are outside the bracket. */
+int mrag_encoder_last_timing(mrag_handle h, float* out_ms);
 
 #ifdef __cplusplus
 }

@@ -53,3 +53,29 @@ def test_param_shapes_cover_hf_names():
     spec = oe.SPECS["tiny"]
     names = set(oe.param_shapes(spec))
     assert "encoder.layer.1.output.LayerNorm.bias" in names and len(names) == 5 + 16 * spec["layers"]
+
+
+def _sha(w):
+    import hashlib
+    h = hashlib.sha256()
+    for k in w:
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("case", ["minilm2", "bge1"])
+def test_oracle_and_weight_generators_match_f6_fixture(golden_dir, case):
+    """F6 = HF BertModel outputs captured by tests/golden/make_golden_encoder.py (MiniLM-L6 / bge-base layer
+    geometry, full vocabulary, 512 positions).  Pins the oracle WITHOUT transformers at run time, and pins
+    the product's weight generator to the one the fixture was made with."""
+    from mrag_amd.encoder import EncoderSpec, seeded_weights
+    z = np.load(golden_dir / "f6_encoder.npz")
+    base = {"minilm2": "minilm-l6", "bge1": "bge-base"}[case]
+    spec = dict(oe.SPECS[base], layers=int(z[f"{case}.layers"]))
+    w = oe.seeded_weights(spec, int(z[f"{case}.seed"]))
+    assert _sha(w) == str(z[f"{case}.weights_sha256"])
+    assert _sha(seeded_weights(EncoderSpec(**spec), int(z[f"{case}.seed"]))) == str(z[f"{case}.weights_sha256"])
+    ids, mask, pool = z[f"{case}.ids"], z[f"{case}.mask"], str(z[f"{case}.pool"])
+    np.testing.assert_allclose(oe.forward(spec, w, ids, mask, pool=pool), z[f"{case}.emb"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(oe.forward(spec, w, ids, mask, pool=pool, normalize=False), z[f"{case}.raw"], rtol=0, atol=2e-4)

@@ -102,10 +102,6 @@ def test_stored_bits_roundtrip_is_verbatim(dtype):
     assert (i1 == i2).all() and (s1 == s2).all()
     if dtype == "f16":
         assert (bits.view(np.float16) == ds.normalize_round(x)).all()      # = the oracle's K1
-        # the round-1 path (cache fp16, renormalise on reload) does move bits: the defect is real
-        again = DenseIndex(200, dtype=dtype)
-        again.add(bits.view(np.float16).astype(np.float32))
-        assert (again.stored_bits() != bits).any()
 
 
 def test_score_rows_matches_oracle_dot():

@@ -67,6 +67,19 @@ def test_bge_base_shape_matches_oracle_cls():
     np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("case", ["minilm2", "bge1"])
+def test_f6_hf_golden(golden_dir, case):
+    """F6: the committed HF BertModel outputs (tests/golden/make_golden_encoder.py) -- MiniLM-L6 / bge-base layer
+    geometry with the full 30 522-row vocabulary and positions up to 272 -- vs the HIP encoder, atol 1e-3."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, seeded_weights
+    z = np.load(golden_dir / "f6_encoder.npz")
+    base = {"minilm2": "minilm-l6", "bge1": "bge-base"}[case]
+    spec = EncoderSpec(**dict(oe.SPECS[base], layers=int(z[f"{case}.layers"])))
+    enc = HipSentenceEncoder(spec, seeded_weights(spec, int(z[f"{case}.seed"])))
+    got = enc.forward(z[f"{case}.ids"], z[f"{case}.mask"], pool=str(z[f"{case}.pool"]))
+    np.testing.assert_allclose(got, z[f"{case}.emb"], rtol=0, atol=TOL)
+
+
 def test_bf16_compute_and_errors():
     from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, ARCHS
     from mrag_amd._native import MragError

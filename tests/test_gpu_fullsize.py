@@ -1,5 +1,6 @@
 """GPU parity at BASELINE.json's full sizes through size-independent properties + oracle subsamples:
-C2 (1k x 100k x 768), C4 shape (10k x 1M x 768), C3 (bge-base-shaped encoder over thousands of passages)."""
+C2 (1k x 100k x 768), C4 shape (10k x 1M x 768), C3 (bge-base encoder, full vocabulary / 512 positions, 64k+
+passages), C5 (IVF-flat nlist 4096 / nprobe 32 over one GPU's 625k x 768 share of the 5M corpus)."""
 import numpy as np
 import pytest
 
@@ -81,27 +82,103 @@ def test_full_size_brute_force(nq, n):
     np.testing.assert_allclose(s1.cpu().numpy(), sc[:3], rtol=0, atol=1e-6)
 
 
-def test_c3_encoder_batch_matches_oracle_subsample():
-    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec
+def test_c3_encoder_full_shape_streamed_batches_match_oracle_subsample():
+    """BASELINE config 3: bge-base shape with the FULL 30 522-row vocabulary and 512 positions, CLS pooling;
+    65 536 passages at S = 64 plus 8 192 at S = 256 and 4 096 at S = 512, streamed in batches; the fp64 oracle
+    (pinned to HF BertModel by F6) on a subsample of the rows that went through the batches, atol 1e-3."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, seeded_weights
     from oracle import encoder as oe
-    spec = dict(oe.SPECS["bge-base"], vocab_size=5000, max_position=128)
-    w = oe.seeded_weights(spec, 3)
-    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w)
+    spec = dict(oe.SPECS["bge-base"])
+    assert spec["vocab_size"] == 30522 and spec["max_position"] == 512
+    es = EncoderSpec(**dict(spec, max_length=512))
+    w = seeded_weights(es, 3)
+    enc = HipSentenceEncoder(es, w)
     rng = np.random.default_rng(1)
-    B, S = 4096, 96
-    ids = rng.integers(5, 5000, size=(B, S)).astype(np.int32)
-    lens = rng.integers(4, S + 1, size=B)
-    mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
-    ids = ids * mask
-    out = np.concatenate([enc.forward(ids[lo:lo + 1024], mask[lo:lo + 1024], pool="cls") for lo in range(0, B, 1024)])
-    assert np.isfinite(out).all()
-    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
-    sub = [0, 1, 777, 2048, 4095]
-    want = oe.forward(spec, w, ids[sub], mask[sub], pool="cls")
-    np.testing.assert_allclose(out[sub], want, rtol=0, atol=1e-3)
-    # batch composition does not change a row (padding rows are masked out)
-    again = enc.forward(ids[sub], mask[sub], pool="cls")
-    np.testing.assert_allclose(again, out[sub], rtol=0, atol=2e-4)
+    for S, n_pass, batch, n_sub in ((64, 65_536, 4096, 6), (256, 8192, 1024, 3), (512, 4096, 512, 2)):
+        sub = sorted(int(x) for x in rng.choice(n_pass, size=n_sub, replace=False))
+        sub[0] = 0
+        sub[-1] = n_pass - 1
+        kept = {}
+        checked = 0
+        for lo in range(0, n_pass, batch):
+            brng = np.random.default_rng(1000 * S + lo)        # every batch reproducible on its own
+            ids = brng.integers(5, spec["vocab_size"], size=(batch, S)).astype(np.int32)
+            lens = brng.integers(2, S + 1, size=batch)
+            lens[0] = S                                        # a full-length row in every batch (positions up to S-1)
+            mask = (np.arange(S)[None, :] < lens[:, None]).astype(np.int32)
+            ids = ids * mask
+            out = enc.forward(ids, mask, pool="cls")
+            assert out.shape == (batch, 768) and np.isfinite(out).all()
+            np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+            for r in sub:
+                if lo <= r < lo + batch:
+                    kept[r] = (ids[r - lo].copy(), mask[r - lo].copy(), out[r - lo].copy())
+            checked += batch
+        assert checked == n_pass and sorted(kept) == sub
+        sid = np.stack([kept[r][0] for r in sub]); smask = np.stack([kept[r][1] for r in sub])
+        want = oe.forward(spec, w, sid, smask, pool="cls")
+        got = np.stack([kept[r][2] for r in sub])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-3)
+        # batch composition does not change a row (padding rows are masked out)
+        again = enc.forward(sid, smask, pool="cls")
+        np.testing.assert_allclose(again, got, rtol=0, atol=2e-4)
+
+
+def test_c5_ivf_flat_per_gpu_share():
+    """BASELINE config 5 on ONE GPU's share: 625 000 x 768 rows (1/8 of the 5M corpus; SURVEY 8e shards rows and
+    replicates the centroids), nlist 4096 trained on the device, nprobe 32, k = 10, clustered data (SURVEY 8d
+    generator).  The reference has no IVF: parity is against the oracle's ivf_search on the SAME centroids and
+    the GPU's own assignments (query subsample), recall@10 against exact brute force, and nprobe = nlist must
+    equal brute force."""
+    import torch
+    from mrag_amd.index import IVFFlatIndex, DenseIndex
+    n, nq, d, nlist, nprobe, k = 625_000, 10_000, 768, 4096, 32, 10
+    rows, qs = ds.make_clustered(n, nq, d, seed=2024, n_centroids=4096)
+    c16, q16 = ds.normalize_round(rows), ds.normalize_round(qs)
+    del rows, qs
+    ix = IVFFlatIndex(d, nlist)
+    ix.train(c16[:: n // 100_000][:100_000], iters=5, seed=1, normalize=False)
+    bf = DenseIndex(d)
+    for lo in range(0, n, 125_000):
+        ix.add(c16[lo:lo + 125_000], normalize=False)
+        bf.add(c16[lo:lo + 125_000], normalize=False)
+    assert len(ix) == n
+    cen = ix.centroids().astype(np.float16)
+    a_gpu = ix.assignments().astype(np.int64)
+    counts = np.bincount(a_gpu, minlength=nlist)
+    assert counts.sum() == n and (counts > 0).mean() > 0.9
+    # assignment parity on a row subsample (argmax over 4096 centroids, fp32 MFMA accumulation vs fp64)
+    rsub = np.arange(0, n, n // 2000)[:2000]
+    cs = c16[rsub].astype(np.float64) @ cen.astype(np.float64).T
+    srt = np.sort(cs, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert (a_gpu[rsub][clear] == np.argmax(cs, axis=1)[clear]).all() and clear.mean() > 0.99
+    sc, ids = ix.search(q16, k, nprobe, normalize=False)
+    t = ix.last_timing()
+    assert t["n_wg"] > 0 and 0 < t["scan_ms"] <= t["total_ms"] and t["scanned_rows"] > 0
+    # oracle on a query subsample
+    sub = np.arange(0, nq, nq // 128)[:128]
+    rv, ri = ds.ivf_search(q16[sub], c16, cen, a_gpu, nprobe, k)
+    np.testing.assert_allclose(sc[sub], rv, rtol=0, atol=1e-5)
+    strict, bad = ds.gap_aware_id_match(ids[sub], sc[sub], ri, rv, tol=1e-5)
+    assert bad <= 0.002 * len(sub) * k, (strict, bad)     # a probe-boundary near-tie may swap one list
+    # recall@10 vs exact brute force, all 10k queries
+    bs, bi = bf.search(q16, k, normalize=False)
+    bv, bri = ds.brute_force_topk(q16[sub[:32]], c16, k)
+    assert ds.gap_aware_id_match(bi[sub[:32]], bs[sub[:32]], bri, bv, tol=1e-5)[1] == 0
+    recall = ds.recall_at_k(ids, bi)
+    print(f"C5 share: recall@10 vs brute force = {recall:.4f}; scan {t['scan_ms']:.2f} ms, search {t['total_ms']:.2f} ms, "
+          f"{t['n_wg']} workgroups, {t['scanned_rows']} rows streamed")
+    assert recall >= 0.99
+    # nprobe = nlist: exhaustive == brute force (64 queries: every list x every query)
+    es, ei = ix.search(q16[:64], k, nlist, normalize=False)
+    np.testing.assert_allclose(es, bs[:64], rtol=0, atol=1e-5)
+    assert ds.gap_aware_id_match(ei, es, bi[:64], bs[:64], tol=1e-5)[1] == 0
+    # nprobe between 64 and 256 goes through the streaming kernel's probe selection
+    ws, wi = ix.search(q16[:24], k, 100, normalize=False)
+    wv, wri = ds.ivf_search(q16[:24], c16, cen, a_gpu, 100, k)
+    np.testing.assert_allclose(ws, wv, rtol=0, atol=1e-5)
+    assert ds.gap_aware_id_match(wi, ws, wri, wv, tol=1e-5)[1] <= 1
 
 
 def test_rccl_exchange_path_single_rank():
