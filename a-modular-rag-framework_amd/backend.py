@@ -150,13 +150,19 @@ class DenseRetrievalBackend:
                  default_top_k: int = 20, dense_pool_k: int = 200, embed_batch: int = 256,
                  cache_dir: Optional[str] = None, device: int = 0, index_dtype: str = "f16",
                  text_search: Optional[Callable[..., List[Dict[str, Any]]]] = None,
-                 graph_expand: Optional[Callable[..., List[Dict[str, Any]]]] = None):
+                 graph_expand: Optional[Callable[..., List[Dict[str, Any]]]] = None,
+                 text_channel: Optional[str] = None, bm25_k1: float = 1.5, bm25_b: float = 0.75):
         self.router, self.sink = router, sink
         self.index_path = index_path
         self.alpha_text, self.alpha_graph, self.alpha_dense = float(alpha_text), float(alpha_graph), float(alpha_dense)
         self.default_top_k, self.dense_pool_k, self.embed_batch = int(default_top_k), int(dense_pool_k), int(embed_batch)
         self.cache_dir, self.device, self.index_dtype = cache_dir, int(device), index_dtype
         self.text_search, self.graph_expand = text_search, graph_expand
+        # text_channel="bm25": the reference's BM25 channel (text_index.py, retrieval_backend.py:102-128) over the same
+        # docs.jsonl, on the device (mrag_amd.text_index), built once per file and shared process-wide
+        self.text_channel, self.bm25_k1, self.bm25_b = text_channel, float(bm25_k1), float(bm25_b)
+        if text_channel not in (None, "bm25"):
+            raise ValueError(f"unknown text_channel {text_channel!r} (supported: 'bm25')")
         self._state = None
 
     # -- corpus index: built once per (file signature, model), shared process-wide --------------
@@ -230,6 +236,16 @@ class DenseRetrievalBackend:
         state["row_of"] = row_of
         return state
 
+    def _bm25_searcher(self):
+        from .text_index import HipBM25Index, HipBM25TextSearcher
+        try:
+            sig = _corpus.file_signature(self.index_path)
+        except OSError:
+            sig = f"{self.index_path}|missing"
+        key = f"bm25-index|{sig}|{self.device}|{self.bm25_k1}|{self.bm25_b}"
+        ix = _corpus.shared(key, lambda: HipBM25Index(self.index_path, k1=self.bm25_k1, b=self.bm25_b, device=self.device))
+        return HipBM25TextSearcher(ix)
+
     _FAIL_BACKOFF_S = 30.0
     _failed: Dict[str, Any] = {}        # key -> (monotonic deadline, error text): no re-embed storm after a failed build
 
@@ -261,6 +277,13 @@ class DenseRetrievalBackend:
 
         t_hits: List[Dict[str, Any]] = []
         g_hits: List[Dict[str, Any]] = []
+        text_error = None
+        if self.text_search is None and self.text_channel == "bm25":
+            try:
+                self.text_search = self._bm25_searcher()
+            except Exception as e:     # degrade like the dense channel: report, keep serving the other channels
+                text_error = repr(e)
+                logger.error("[DenseRetrievalBackend] BM25 channel unavailable: %s", e)
         if self.text_search is not None:
             with span("Backend/TextSearch", self.sink, trace_id):
                 t_hits = list(self.text_search(queries=[req.query], top_k=pool) or [])
@@ -316,6 +339,7 @@ class DenseRetrievalBackend:
             "resolved_embed_model": model_hint,
             "dense_backend": "mrag_amd.DenseIndex",
             "dense_error": dense_error,
+            "text_error": text_error,
         }
         return {"hits": fused, "diagnostics": diagnostics}
 

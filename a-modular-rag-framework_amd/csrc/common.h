@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...);
 // verifies a usable device and makes it current
 int use_device(int device);
 
-enum HandleKind : uint32_t { KIND_BF_INDEX = 1, KIND_IVF = 2, KIND_ENCODER = 3 };
+enum HandleKind : uint32_t { KIND_BF_INDEX = 1, KIND_IVF = 2, KIND_ENCODER = 3, KIND_BM25 = 4 };
 
 struct Object {
   HandleKind kind;

@@ -180,6 +180,23 @@ int mrag_encoder_forward(mrag_handle h, const int32_t* ids, const int32_t* mask,
  * hipEvents on its stream; the ids/mask H2D and the output D2H are outside the bracket. */
 int mrag_encoder_last_timing(mrag_handle h, float* out_ms);
 
+/* ---- 8f-3: the BM25 text channel on the device -------------------------------------
+ * Replaces BM25LiteIndex.search (app/modules/retrieval/text_index.py:59-97: per candidate document
+ * _score_doc over the query tokens, max / sum merge over the expanded queries, sort descending, top_k) and
+ * feeds the fusion of retrieval_backend.py:353-372.  The index is built on the host exactly like
+ * text_index.py:36-52 (same tokeniser, tf / df / doc_lens / avgdl) and uploaded as CSR postings:
+ *   indptr[n_terms+1], post_doc[nnz] (ascending inside a term), post_tf[nnz],
+ *   doc_norm[d] = k1 * (1 - b + b * dl_d / avgdl)   (the length term of :66), k1_plus_1 = k1 + 1.
+ * search: n_queries token lists (q_ptr[n_queries+1] into q_terms / q_idf; a token outside the vocabulary is
+ * id -1; q_idf = the reference's _idf of that token, :54-56).  fp64 throughout; a document's score is the
+ * reference's left-to-right sum bit for bit.  merge_sum = 0: max over the queries (alpha_merge="max"), 1: sum.
+ * Output: out_n <= k (doc, score) pairs, (score desc, doc asc), scores > 0 only.  Host buffers. */
+int mrag_bm25_create(int device, int64_t n_docs, int64_t n_terms, const int64_t* indptr, const int32_t* post_doc,
+                     const int32_t* post_tf, const double* doc_norm, double k1_plus_1, mrag_handle* out);
+int mrag_bm25_destroy(mrag_handle h);
+int mrag_bm25_search(mrag_handle h, int n_queries, const int32_t* q_ptr, const int32_t* q_terms, const double* q_idf,
+                     int merge_sum, int k, int64_t* out_docs, double* out_scores, int* out_n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
