@@ -49,6 +49,7 @@ SIGNATURES = {
     "mrag_device_count": [C.POINTER(_i)],
     "mrag_cosine_f64": [_i, _vp, _vp, _i64, _i, _vp, _i, _vp],
     "mrag_cosine_matrix_f64": [_i, _vp, _i64, _i, _vp, _i, _vp],
+    "mrag_cosine_adjacent_f64": [_i, _vp, _i64, _i, C.c_double, _vp, _vp],
     "mrag_index_create": [_i, _i, _i, _i, C.POINTER(_h)],
     "mrag_index_destroy": [_h],
     "mrag_index_reserve": [_h, _i64],

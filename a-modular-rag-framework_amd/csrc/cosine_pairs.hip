@@ -58,9 +58,51 @@ __global__ __launch_bounds__(256) void cosine_matrix_f64_kernel(const double* __
   }
 }
 
+// adjacent rows: out[i] = dot(x_i, x_{i+1}) / (|x_i| |x_{i+1}| + eps) -- the cut rule of embed-mode segmentation
+// (app/modules/graph_construction/segmenter.py:40-42: eps = 1e-9 inside the denominator, no zero-norm branch)
+__global__ __launch_bounds__(256) void cosine_adjacent_f64_kernel(const double* __restrict__ x, int64_t n, int dim, double eps,
+                                                                  double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i + 1 >= n) return;
+  const double *a = x + i * (int64_t)dim, *b = a + dim;
+  double dot = 0.0, aa = 0.0, bb = 0.0;
+  for (int t = lane; t < dim; t += 64) {
+    const double u = a[t], v = b[t];
+    dot += u * v; aa += u * u; bb += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    dot += __shfl_xor(dot, off); aa += __shfl_xor(aa, off); bb += __shfl_xor(bb, off);
+  }
+  if (lane == 0) out[i] = dot / (sqrt(aa) * sqrt(bb) + eps);
+}
+
 }  // namespace mrag
 
 using namespace mrag;
+
+extern "C" int mrag_cosine_adjacent_f64(int device, const double* x, int64_t n, int dim, double eps, double* out, void* stream_) {
+  if (n < 0 || dim <= 0) return fail(MRAG_ERR_INVALID, "bad shape n=%lld dim=%d", (long long)n, dim);
+  if (n < 2) return MRAG_OK;
+  if (!x || !out) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  MRAG_TRY(use_device(device));
+  hipStream_t stream = (hipStream_t)stream_;
+  void* tmp = nullptr;
+  const size_t xb = (size_t)n * dim * 8, ob = (size_t)(n - 1) * 8;
+  MRAG_HIP(hipMalloc(&tmp, xb + ob));
+  hipError_t e = hipMemcpyAsync(tmp, x, xb, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cosine_adjacent_f64_kernel, dim3((unsigned)((n + 2) / 4)), dim3(256), 0, stream, (const double*)tmp, n, dim, eps,
+                       (double*)((char*)tmp + xb));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, (char*)tmp + xb, ob, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(MRAG_ERR_HIP, "cosine_adjacent_f64 failed: %s", hipGetErrorString(e));
+  return MRAG_OK;
+}
 
 extern "C" int mrag_cosine_matrix_f64(int device, const double* x, int64_t n, int dim, double* out, int is_device, void* stream_) {
   if (n < 0 || dim <= 0 || n > 32768) return fail(MRAG_ERR_INVALID, "bad shape n=%lld dim=%d (n <= 32768)", (long long)n, dim);

@@ -6,6 +6,14 @@
 ``mmr_diversify``   greedy MMR (app/utils/similarity.py:33-62) with the candidate x candidate
                     similarities taken from ONE all-pairs launch instead of O(k*n) Python cosines.
 Both run ``mrag_cosine_matrix_f64`` (fp64 on the GPU, zero-norm rows -> 0.0).
+
+``segment_context`` embed-mode segmentation (app/modules/graph_construction/segmenter.py:10-57): sentences of a
+                    title are merged while the cosine of ADJACENT sentence embeddings stays >= the threshold.
+                    All sentences of the context are embedded in one batch and the adjacent cosines come from
+                    one launch (``mrag_cosine_adjacent_f64``) instead of one embed call + numpy per sentence.
+``BatchedEmbedFn``  the ``embed_fn: text -> vector`` callable the reference's graph-construction hooks expect
+                    (edge_builder.py:26,146-152; node_builder.py:56 ``policy["embed_fn"]``; segmenter.py:14) but
+                    nothing in the reference ever supplies, backed by this package's provider.
 """
 from __future__ import annotations
 
@@ -73,3 +81,81 @@ def mmr_diversify(items: Sequence[Tuple[str, float, Optional[Sequence[float]]]],
         bid = items[best][0]
         pool = [c for c in pool if items[c][0] != bid]
     return [items[c] for c in chosen]
+
+
+def cosine_adjacent(vectors, eps: float = 1e-9, device: int = 0) -> np.ndarray:
+    """out[i] = dot(x_i, x_{i+1}) / (|x_i| |x_{i+1}| + eps) (segmenter.py:40-42), fp64 on the GPU."""
+    x = np.ascontiguousarray(vectors, dtype=np.float64)
+    if x.ndim != 2:
+        raise ValueError("expected [n, d] vectors")
+    out = np.empty(max(0, x.shape[0] - 1), dtype=np.float64)
+    if x.shape[0] >= 2:
+        N.check(N.load().mrag_cosine_adjacent_f64(device, x.ctypes.data, x.shape[0], x.shape[1], float(eps), out.ctypes.data, None))
+    return out
+
+
+class BatchedEmbedFn:
+    """``embed_fn(text) -> List[float]`` for the reference's graph-construction hooks, served from a cache that
+    :meth:`prime` fills with ONE provider batch (the hooks call it once per sentence; an encoder forward per
+    sentence would waste the GPU).  ``provider``: anything with ``embed(model=, texts=, require=)`` (this
+    package's ``HipEmbeddingProvider``) or a router-like object with ``embed(model_hint=, texts=, require=)``."""
+
+    def __init__(self, provider, model: Optional[str] = None, trace_id: str = "graph-construction"):
+        self.provider, self.model, self.trace_id = provider, model, trace_id
+        self.cache = {}
+
+    def _embed(self, texts: List[str]) -> List[List[float]]:
+        if hasattr(self.provider, "policy"):       # an LLMRouter
+            ret = self.provider.embed(model_hint=self.model or "", texts=texts, require={"trace_id": self.trace_id})
+        else:
+            ret = self.provider.embed(model=self.model, texts=texts, require={"trace_id": self.trace_id})
+        return ret.get("vectors") if isinstance(ret, dict) else ret
+
+    def prime(self, texts: Sequence[str]) -> None:
+        todo = [t for t in dict.fromkeys(texts) if t not in self.cache]
+        if todo:
+            for t, v in zip(todo, self._embed(todo)):
+                self.cache[t] = [float(x) for x in v]
+
+    def __call__(self, text: str) -> List[float]:
+        if text not in self.cache:
+            self.prime([text])
+        return self.cache[text]
+
+
+def segment_context(ctx: Sequence[Tuple[str, List[str]]], *, strategy: str = "rule", embed_fn=None,
+                    sim_threshold: float = 0.65, device: int = 0) -> List[Tuple[str, List[str]]]:
+    """``segment_context`` of the reference (segmenter.py:10-57), same arguments and results.  ``rule``: split on
+    sentence punctuation (:5-7); ``embed`` with an ``embed_fn``: start a new segment where the adjacent-sentence
+    similarity falls below ``sim_threshold``; anything else: sentences unchanged.  In embed mode every sentence
+    of the context is embedded up front (one batch when ``embed_fn`` is a :class:`BatchedEmbedFn`) and all
+    adjacent similarities come from one GPU launch."""
+    import re
+    ctx = [(title, list(sents)) for title, sents in ctx]
+    sims = None
+    if strategy == "embed" and embed_fn:
+        flat = [s for _, sents in ctx for s in sents]
+        if isinstance(embed_fn, BatchedEmbedFn):
+            embed_fn.prime(flat)
+        vecs = [embed_fn(s) for s in flat]
+        if len(flat) >= 2:
+            sims = cosine_adjacent(np.asarray(vecs, dtype=np.float64), 1e-9, device)
+    out: List[Tuple[str, List[str]]] = []
+    at = 0
+    for title, sents in ctx:
+        if strategy == "rule":
+            new = [p.strip() for s in sents for p in re.split(r"[。！？.!?]", s) if p.strip()]
+        elif strategy == "embed" and embed_fn:
+            new, batch = [], []
+            for i, s in enumerate(sents):
+                if i > 0 and float(sims[at + i - 1]) < sim_threshold:     # :43-46 (never cuts before a title's first sentence)
+                    new.append(" ".join(batch))
+                    batch = []
+                batch.append(s)
+            if batch:
+                new.append(" ".join(batch))
+            at += len(sents)
+        else:
+            new = list(sents)
+        out.append((title, new))
+    return out

@@ -65,6 +65,10 @@ int mrag_cosine_f64(int device, const double* query, const double* cands, int64_
  * edge_builder.py:146-169: per pair three norms + one dot, edge if sim >= threshold) and the
  * pairwise term of MMR (app/utils/similarity.py:33-62) in one launch instead of n^2 Python calls. */
 int mrag_cosine_matrix_f64(int device, const double* x, int64_t n, int dim, double* out, int is_device, void* stream);
+/* adjacent rows (embed-mode segmentation, app/modules/graph_construction/segmenter.py:32-50):
+ * out[i] = dot(x_i, x_{i+1}) / (|x_i| * |x_{i+1}| + eps) for i < n-1 -- eps = 1e-9 sits INSIDE the denominator
+ * there and a zero vector gives 0/eps = 0, not a special case.  Host buffers, fp64. */
+int mrag_cosine_adjacent_f64(int device, const double* x, int64_t n, int dim, double eps, double* out, void* stream);
 
 /* ---- a7 at corpus scale: brute-force cosine / inner-product top-k ----------------
  * Replaces "score every candidate, sort descending, truncate" --

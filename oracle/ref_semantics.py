@@ -302,3 +302,12 @@ def read_docs_jsonl(path: str) -> List[Dict[str, Any]]:
             if line:
                 rows.append(json.loads(line))
     return rows
+
+
+# ---------------------------------------------------------------------- 8f-2 (segmentation)
+def adjacent_similarity(va: Sequence[float], vb: Sequence[float]) -> float:
+    """The cut test of embed-mode segmentation -- app/modules/graph_construction/segmenter.py:40-42:
+    ``dot / (|a| * |b| + 1e-9)`` (epsilon inside the denominator; zero vectors give 0.0)."""
+    import numpy as np
+    a, b = np.array(va), np.array(vb)
+    return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-9))

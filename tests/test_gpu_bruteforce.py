@@ -251,6 +251,25 @@ def test_pairwise_next_rows_semantic_edges_and_mmr(golden_dir):
         assert [x[0] for x in sel] == c["selected_ids"]          # == the reference's own selections (fixture F4)
 
 
+def test_f8_segmentation_on_the_adjacent_cosine_kernel(golden_dir):
+    """embed-mode segment_context (segmenter.py:32-50, eps inside the denominator) on the GPU kernel
+    vs F8 = the reference's own segment_context outputs, and the kernel vs the reference formula."""
+    import json
+    from mrag_amd.pairwise import segment_context, cosine_adjacent
+    from oracle import ref_semantics as rs
+    d = json.loads((golden_dir / "f8_segment.json").read_text())
+    table = d["table"]
+    ctx = [(t, s) for t, s in d["ctx"]]
+    for c in d["cases"]:
+        fn = None if c.get("no_embed_fn") else (lambda s: table[s])
+        got = segment_context(ctx, strategy=c["strategy"], embed_fn=fn, sim_threshold=c["sim_threshold"])
+        assert [[t, s] for t, s in got] == c["out"], (c["strategy"], c["sim_threshold"])
+    v = np.asarray(list(table.values()), dtype=np.float64)
+    want = np.asarray([rs.adjacent_similarity(v[i], v[i + 1]) for i in range(len(v) - 1)])
+    np.testing.assert_allclose(cosine_adjacent(v), want, rtol=0, atol=1e-14)
+    assert cosine_adjacent(v[:1]).shape == (0,)
+
+
 @pytest.mark.parametrize("nq,n,d,k", [(1, 100000, 768, 20), (16, 70001, 384, 10), (5, 9000, 64, 64), (2, 2048, 128, 1)])
 def test_online_regime_streaming_kernel(nq, n, d, k):
     """<= 16 queries take the HBM-streaming kernel (K2s): same exactness bars."""

@@ -192,3 +192,32 @@ def test_dto_shapes():
     h = Hit(id="a", score=1)
     assert h.meta == {} and isinstance(h.score, float)
     assert RetrievalOut().hits == [] and RetrievalOut().diagnostics == {}
+
+
+def test_f8_segment_context_matches_reference(golden_dir, monkeypatch):
+    """segment_context (segmenter.py:10-57) -- rule / embed / passthrough -- against F8, the
+    reference's own outputs.  The GPU adjacent-cosine kernel is replaced by the oracle formula here (CPU); the
+    kernel itself is checked in tests/test_gpu_bruteforce.py."""
+    import mrag_amd.pairwise as pw
+    d = json.loads((golden_dir / "f8_segment.json").read_text())
+    table = d["table"]
+
+    def fake_adjacent(vectors, eps=1e-9, device=0):
+        v = np.asarray(vectors, dtype=np.float64)
+        return np.asarray([rs.adjacent_similarity(v[i], v[i + 1]) for i in range(len(v) - 1)])
+    monkeypatch.setattr(pw, "cosine_adjacent", fake_adjacent)
+    ctx = [(t, s) for t, s in d["ctx"]]
+    for c in d["cases"]:
+        fn = None if c.get("no_embed_fn") else (lambda s: table[s])
+        got = pw.segment_context(ctx, strategy=c["strategy"], embed_fn=fn, sim_threshold=c["sim_threshold"])
+        assert [[t, s] for t, s in got] == c["out"], (c["strategy"], c["sim_threshold"])
+
+    class Prov:                                   # BatchedEmbedFn: one provider batch for the whole context
+        calls = []
+        def embed(self, *, model, texts, require):
+            Prov.calls.append(len(texts))
+            return {"vectors": [table[t] for t in texts]}
+    fn = pw.BatchedEmbedFn(Prov(), model="m")
+    got = pw.segment_context(ctx, strategy="embed", embed_fn=fn, sim_threshold=0.65)
+    assert [[t, s] for t, s in got] == d["cases"][0]["out"]
+    assert len(Prov.calls) == 1 and fn("zero") == table["zero"] and len(Prov.calls) == 1
