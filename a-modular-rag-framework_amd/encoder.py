@@ -206,14 +206,46 @@ class HipSentenceEncoder:
             mask[i, :len(s)] = 1
         return ids, mask
 
-    def encode(self, texts: List[str], batch_size: int = 256, normalize: bool = True) -> np.ndarray:
-        """Texts -> [n, hidden] float32.  Batches are formed in length order (less padding) and the
-        rows are returned in input order."""
+    def encode(self, texts: List[str], batch_size: int = 256, normalize: bool = True, overlap: bool = True) -> np.ndarray:
+        """Texts -> [n, hidden] float32.  Batches are formed in length order (less padding) and the rows are
+        returned in input order.  ``overlap``: a tokeniser thread prepares batch i+1 (WordPiece /
+        hashing, padding) while the GPU runs batch i -- the forward is one ctypes call, which releases the GIL for
+        its whole duration -- so host tokenisation leaves the timeline when the GPU is the slower side."""
         n = len(texts)
         out = np.empty((n, self.spec.hidden), dtype=np.float32)
         order = sorted(range(n), key=lambda i: len(texts[i]))
-        for lo in range(0, n, batch_size):
-            sel = order[lo:lo + batch_size]
-            ids, mask = self.tokenize([texts[i] for i in sel])
-            out[sel] = self.forward(ids, mask, normalize=normalize)
+        batches = [order[lo:lo + batch_size] for lo in range(0, n, batch_size)]
+        if not overlap or len(batches) < 2:
+            for sel in batches:
+                ids, mask = self.tokenize([texts[i] for i in sel])
+                out[sel] = self.forward(ids, mask, normalize=normalize)
+            return out
+        import queue
+        import threading
+        ready: "queue.Queue" = queue.Queue(maxsize=2)       # at most two tokenised batches ahead of the GPU
+
+        def produce():
+            try:
+                for sel in batches:
+                    ready.put((sel,) + self.tokenize([texts[i] for i in sel]))
+                ready.put(None)
+            except BaseException as e:                        # surface tokeniser errors in the caller
+                ready.put(e)
+        t = threading.Thread(target=produce, name="mrag-tokenizer", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                sel, ids, mask = item
+                out[sel] = self.forward(ids, mask, normalize=normalize)
+        finally:
+            while t.is_alive():                               # unblock the producer if the consumer bailed out early
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    t.join(0.01)
         return out

@@ -221,3 +221,47 @@ def test_f8_segment_context_matches_reference(golden_dir, monkeypatch):
     got = pw.segment_context(ctx, strategy="embed", embed_fn=fn, sim_threshold=0.65)
     assert [[t, s] for t, s in got] == d["cases"][0]["out"]
     assert len(Prov.calls) == 1 and fn("zero") == table["zero"] and len(Prov.calls) == 1
+
+
+def test_encode_overlaps_tokenisation_with_the_forward(monkeypatch):
+    """SURVEY 8f-4: the tokeniser thread prepares batch i+1 while the (stubbed) GPU forward of batch i runs;
+    results are identical to the serial path, errors surface in the caller."""
+    import threading
+    import time
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, ARCHS, HashingTokenizer
+
+    enc = object.__new__(HipSentenceEncoder)                 # no GPU: bypass __init__, stub the forward
+    enc.spec = EncoderSpec(**ARCHS["tiny"])
+    enc.max_length, enc.tokenizer, enc._h = 32, HashingTokenizer(1000), None
+    log = []
+
+    def slow_tokenize(texts, _orig=HipSentenceEncoder.tokenize):
+        log.append(("tok+", time.perf_counter(), threading.current_thread().name))
+        time.sleep(0.03)
+        r = _orig(enc, texts)
+        log.append(("tok-", time.perf_counter(), threading.current_thread().name))
+        return r
+
+    def fake_forward(ids, mask, pool=None, normalize=True):
+        log.append(("fwd+", time.perf_counter(), threading.current_thread().name))
+        time.sleep(0.05)                                      # the ctypes call releases the GIL like sleep does
+        log.append(("fwd-", time.perf_counter(), threading.current_thread().name))
+        return np.stack([np.full(64, float(ids[i].sum())) for i in range(ids.shape[0])]).astype(np.float32)
+    enc.tokenize, enc.forward = slow_tokenize, fake_forward
+    texts = [f"word{i} " * (1 + i % 7) for i in range(40)]
+    t0 = time.perf_counter(); a = enc.encode(texts, batch_size=8, overlap=True); t_overlap = time.perf_counter() - t0
+    names = {n for k, _, n in log if k.startswith("tok")}
+    assert names == {"mrag-tokenizer"}
+    # some tokenisation interval lies inside a forward interval
+    fwd = [(s[1], e[1]) for s, e in zip([x for x in log if x[0] == "fwd+"], [x for x in log if x[0] == "fwd-"])]
+    tok = [(s[1], e[1]) for s, e in zip([x for x in log if x[0] == "tok+"], [x for x in log if x[0] == "tok-"])]
+    assert any(fs < ts and te < fe + 0.03 for ts, te in tok for fs, fe in fwd)
+    log.clear()
+    t0 = time.perf_counter(); b = enc.encode(texts, batch_size=8, overlap=False); t_serial = time.perf_counter() - t0
+    assert np.array_equal(a, b) and t_overlap < t_serial - 0.05      # 5 batches: ~4 x 30 ms of tokenisation hidden
+
+    def bad_tokenize(texts):
+        raise ValueError("tokenizer failed")
+    enc.tokenize = bad_tokenize
+    with pytest.raises(ValueError, match="tokenizer failed"):
+        enc.encode(texts, batch_size=8)
