@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 
   for (int ti = 0; ti < n_tiles; ++ti) {
 #ifdef MRAG_DIAG
-    stamp_on = ti >= 60 && ti < 66;
+    stamp_on = DESC || (ti >= 60 && ti < 66);   // descriptor mode (IVF): one or two tiles per workgroup, stamp them all
     MRAG_STAMP(2);
 #endif
     kstep(std::false_type{});
@@ -1465,6 +1465,21 @@ struct BfIndex : Object {
 static long long* g_stamps = nullptr;  // diagnostic s_memtime stamps (MRAG_DEBUG_FLAGS & 16)
 #endif
 
+#ifdef MRAG_DIAG
+static int dump_stamps(int dbg, hipStream_t stream) {
+  if (!g_stamps || !(dbg & 16)) return MRAG_OK;
+  long long hs[128];
+  MRAG_HIP(hipStreamSynchronize(stream));
+  MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+  fprintf(stderr, "[mrag tail] first pass of 16 queries, cycles from its start: loads issued %lld, parked %lld; query 0 staged %lld ranked %lld; q1 %lld %lld; q2 %lld %lld; q3 %lld %lld; pass done %lld\n",
+          hs[101], hs[102], hs[103], hs[104], hs[105], hs[106], hs[107], hs[108], hs[109], hs[110], hs[111]);
+  fprintf(stderr, "[mrag stamps]");
+  for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i) fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
+  fprintf(stderr, "\n");
+  return MRAG_OK;
+}
+#endif
+
 static size_t dtype_size(int dt) {
   switch (dt) { case MRAG_F32: return 4; case MRAG_F16: case MRAG_BF16: return 2; case MRAG_F64: return 8; default: return 0; }
 }
@@ -1571,6 +1586,9 @@ int bf_launch(const BfLaunch& a) {
     p.counts = (int*)a.counts->p;
     MRAG_TRY(launch_k2(a.dtype, grid, stream, p));
     if (a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+#ifdef MRAG_DIAG
+    MRAG_TRY(dump_stamps(p.dbg, stream));
+#endif
     MergeParams mp;
     mp.list = p.list; mp.counts = p.counts;
     mp.T = 0; mp.S = 0; mp.k = a.k; mp.nq = a.nq; mp.id_base = a.id_base;
@@ -1651,16 +1669,7 @@ int bf_launch(const BfLaunch& a) {
     hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)nq), dim3(64), 0, stream, mp);
     MRAG_HIP(hipGetLastError());
 #ifdef MRAG_DIAG
-    if (g_stamps && (p.dbg & 16)) {
-      long long hs[128];
-      MRAG_HIP(hipStreamSynchronize(stream));
-      MRAG_HIP(hipMemcpy(hs, g_stamps, sizeof(hs), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[mrag tail] first pass of 16 queries, cycles from its start: loads issued %lld, parked %lld; query 0 staged %lld ranked %lld; q1 %lld %lld; q2 %lld %lld; q3 %lld %lld; pass done %lld\n",
-              hs[101], hs[102], hs[103], hs[104], hs[105], hs[106], hs[107], hs[108], hs[109], hs[110], hs[111]);
-      fprintf(stderr, "[mrag stamps]");
-      for (int i = 0; i < 64 && (i == 0 || hs[2 * i + 1]); ++i) fprintf(stderr, " %lld:%lld", hs[2 * i], hs[2 * i + 1] - hs[1]);
-      fprintf(stderr, "\n");
-    }
+    MRAG_TRY(dump_stamps(p.dbg, stream));
 #endif
   }
   return MRAG_OK;

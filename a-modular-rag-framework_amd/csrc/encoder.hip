@@ -285,6 +285,13 @@ __global__ __launch_bounds__(GTHR) void enc_gemm_kernel(const uint16_t* __restri
 // The WEIGHT rows are the MFMA A operand and the token rows the B operand, so a lane's four accumulator
 // values are four consecutive OUTPUT columns of one token: bias / GELU / residual apply to 8-byte
 // groups and the stores are 8 bytes per lane (the 128 x 128 kernel above stores 2 bytes at a time).
+// Timing-only ablations of the 256 x 256 GEMM (make ENCDIAG=<flags>; results are wrong by design):
+//   1 no epilogue at all | 2 epilogue without the global stores | 4 no GELU | 8 no residual / bias loads
+#ifdef MRAG_ENC_DIAG
+#define ENC_DBG(bit) ((MRAG_ENC_DIAG) & (bit))
+#else
+#define ENC_DBG(bit) 0
+#endif
 constexpr int G2_T = 256, G2_THR = 512;
 constexpr int G2_A_BYTES = G2_T * GK * 2;            // 32 KiB: weight rows of a stage
 constexpr int G2_STAGE = 2 * G2_A_BYTES;             // 64 KiB
@@ -296,11 +303,21 @@ constexpr int G2_CPITCH = 528;                        // output row pitch in LDS
 template <int DT, int EPI>
 __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                                 const float* __restrict__ bias, const uint16_t* __restrict__ R,
-                                                                uint16_t* __restrict__ C, int N, int K, int tiles_m, int tiles_n) {
+                                                                uint16_t* __restrict__ C, int N, int K, int tiles_m, int tiles_n,
+                                                                int stagger) {
   typedef typename EMfma<DT>::frag frag;
   typedef typename EMfma<DT>::elem elem;
   typedef elem e4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char sm2[];
+  // Every workgroup walks tiles of the same length, so left alone all 256 reach their epilogue together and
+  // the chip alternates between "nobody stores" and a 32 MB store burst that HBM drains while every MFMA pipe
+  // waits.  Start the XCDs (blockIdx % 8: the workgroups that share an L2 stay in step) `stagger` cycles apart,
+  // an eighth of a tile each, so that the bursts of the eight XCDs tile the time axis instead of stacking.
+  if (stagger > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 2, wn = w & 3;     // wave tile: 128 weight rows (output columns) x 64 tokens
@@ -428,29 +445,51 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
     const int n_l = wm * 128 + (lane >> 4) * 4;             // + mf*16: column inside the tile
     const int n_b = tn * G2_T + n_l;
     const int t_b = tm * G2_T + wn * 64 + (lane & 15);
+    if (ENC_DBG(1)) {   // ablation: keep the accumulators observable, skip the epilogue
+      float xs = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) xs += acc[mf][nf][0] + acc[mf][nf][1] + acc[mf][nf][2] + acc[mf][nf][3];
+      if (xs == 123456.789f) C[0] = 1;
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    // Every global load of the epilogue is issued HERE, back to back, and waited for once: written inside the
+    // passes, hipcc puts an s_waitcnt vmcnt(0) behind each of them (8 bias + 32 residual loads = up to 40 serial
+    // L2 round trips per tile), and in pass 1 that wait also sits out pass 0's stores (vmcnt counts in order).
+    float4 bv[8];
+    e4 rr[8][4];
+#pragma unroll
+    for (int mf = 0; mf < 8; ++mf) {
+      const int n0 = n_b + mf * 16;
+      bv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 < N && !ENC_DBG(8)) bv[mf] = *(const float4*)(bias + n0);
+      if (EPI == EPI_RESID && !ENC_DBG(8)) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          rr[mf][nf] = (e4){(elem)0.f, (elem)0.f, (elem)0.f, (elem)0.f};
+          if (n0 < N) rr[mf][nf] = *(const e4*)(R + (size_t)(t_b + nf * 16) * N + n0);
+        }
+      }
+    }
     __builtin_amdgcn_s_barrier();   // every wave has read its last fragments out of the buffer the slab reuses (lgkmcnt(0) in kstep)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) {
-        const int n0 = n_b + mf * 16;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 < N) bv = *(const float4*)(bias + n0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int nf = pass * 2 + h;
-          float v[4] = {acc[mf][nf][0] + bv.x, acc[mf][nf][1] + bv.y, acc[mf][nf][2] + bv.z, acc[mf][nf][3] + bv.w};
-          if (EPI == EPI_GELU) {
+          float v[4] = {acc[mf][nf][0] + bv[mf].x, acc[mf][nf][1] + bv[mf].y, acc[mf][nf][2] + bv[mf].z, acc[mf][nf][3] + bv[mf].w};
+          if (EPI == EPI_GELU && !ENC_DBG(4)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
           }
-          if (EPI == EPI_RESID) {
-            if (n0 < N) {
-              const e4 rr = *(const e4*)(R + (size_t)(t_b + nf * 16) * N + n0);
+          if (EPI == EPI_RESID && !ENC_DBG(8)) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[mf][nf][r];
           }
           e4 o;
 #pragma unroll
@@ -459,7 +498,11 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
           *(e4*)(slab + tl * G2_CPITCH + (n_l + mf * 16) * 2) = o;
         }
       }
-      __syncthreads();
+      // raw barriers behind LDS-only waits: the global stores below stay in flight across them (a
+      // __syncthreads() here drains them: a full HBM write round trip per pass with every CU storing at once)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = tid + G2_THR * i;                      // 128 rows x 32 sixteen-byte pieces
@@ -468,14 +511,14 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
         if (n0 < N) {
           const int token = tm * G2_T + (row >> 5) * 64 + pass * 32 + (row & 31);
           const uint4 val = *(const uint4*)(slab + row * G2_CPITCH + piece * 16);
-          *(uint4*)(C + (size_t)token * N + n0) = val;
+          if (!ENC_DBG(2)) *(uint4*)(C + (size_t)token * N + n0) = val;
+          else if (val.x == 0x12345678u && val.y == 0x9abcdef0u) C[0] = 1;
         }
       }
-      if (pass == 0) __syncthreads();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done (pass 1 rewrites it; after pass 1 the next stage lands in it)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();      // every wave's loads of the next first stage have landed (waited above)
-    asm volatile("" ::: "memory");
   }
 }
 
@@ -731,12 +774,13 @@ static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hi
 }
 
 // development switch (MRAG_ENC_GEMM128=1): force the 128 x 128 kernel, for A/B timing
+static const int g_stagger_override = [] { const char* e = getenv("MRAG_ENC_STAGGER"); return e ? atoi(e) : -1; }();   // experiment knob
 static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM128"); return e && atoi(e) != 0; }();
 
 template <int DT>
 static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M_pad, int epi, hipStream_t stream) {
   if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && !g_force_gemm128) {
-    typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int);
+    typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int, int);
     const Fn fn = epi == EPI_BIAS ? (Fn)enc_gemm256_kernel<DT, EPI_BIAS> : epi == EPI_GELU ? (Fn)enc_gemm256_kernel<DT, EPI_GELU>
                                                                                           : (Fn)enc_gemm256_kernel<DT, EPI_RESID>;
     static std::map<const void*, bool> attr_done;
@@ -748,7 +792,12 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
     int cus = 256;
     { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
     const int nwg = std::min(tm2 * tn2, cus);
-    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2);
+    // XCD start stagger: an eighth of a tile's main loop (~3000 cycles per K step) per XCD, only when every
+    // workgroup has several tiles to walk (the delay is paid once per launch)
+    const int per_wg = (tm2 * tn2 + nwg - 1) / nwg;
+    int stagger = (nwg % 8 == 0 && per_wg >= 8) ? (l.K / GK) * 3000 / 8 : 0;
+    if (g_stagger_override >= 0) stagger = (nwg % 8 == 0) ? g_stagger_override : 0;
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2, stagger);
     MRAG_HIP(hipGetLastError());
     return MRAG_OK;
   }
