@@ -80,6 +80,7 @@ SIGNATURES = {
     "mrag_bm25_create": [_i, _i64, _i64, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(_h)],
     "mrag_bm25_destroy": [_h],
     "mrag_bm25_search": [_h, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_i), _vp],
+    "mrag_fuse_topk": [_i, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, C.c_double, _i, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i), _vp],
     "mrag_encoder_create": [C.POINTER(EncoderConfig), _i, C.POINTER(_h)],
     "mrag_encoder_destroy": [_h],
     "mrag_encoder_set_param": [_h, C.c_char_p, _vp, _i64, _i, _vp],

@@ -151,7 +151,8 @@ class DenseRetrievalBackend:
                  cache_dir: Optional[str] = None, device: int = 0, index_dtype: str = "f16",
                  text_search: Optional[Callable[..., List[Dict[str, Any]]]] = None,
                  graph_expand: Optional[Callable[..., List[Dict[str, Any]]]] = None,
-                 text_channel: Optional[str] = None, bm25_k1: float = 1.5, bm25_b: float = 0.75):
+                 text_channel: Optional[str] = None, bm25_k1: float = 1.5, bm25_b: float = 0.75,
+                 fuse_on_device: bool = False):
         self.router, self.sink = router, sink
         self.index_path = index_path
         self.alpha_text, self.alpha_graph, self.alpha_dense = float(alpha_text), float(alpha_graph), float(alpha_dense)
@@ -161,6 +162,7 @@ class DenseRetrievalBackend:
         # text_channel="bm25": the reference's BM25 channel (text_index.py, retrieval_backend.py:102-128) over the same
         # docs.jsonl, on the device (mrag_amd.text_index), built once per file and shared process-wide
         self.text_channel, self.bm25_k1, self.bm25_b = text_channel, float(bm25_k1), float(bm25_b)
+        self.fuse_on_device = bool(fuse_on_device)     # a7's arithmetic in one launch (mrag_fuse_topk) instead of host Python
         if text_channel not in (None, "bm25"):
             raise ValueError(f"unknown text_channel {text_channel!r} (supported: 'bm25')")
         self._state = None
@@ -321,8 +323,11 @@ class DenseRetrievalBackend:
         # dense hits double as candidates (their meta gives the normalised id); scores fused per :350-372
         dense_norm_hits = _fusion.dedupe_by_norm_id(dense_hits)
         dense_scores = {nid: h["score"] for nid, h in dense_norm_hits.items()}
-        fused = _fusion.fuse_channels(t_hits, g_hits, dense_scores, alpha_text=self.alpha_text,
-                                      alpha_graph=self.alpha_graph, alpha_dense=self.alpha_dense, top_k=10 ** 9)
+        fuse = _fusion.fuse_channels
+        if self.fuse_on_device and len(t_hits) + len(g_hits) + len(dense_scores) <= 4096:
+            fuse = lambda *a, **kw: _fusion.fuse_channels_device(*a, device=self.device, **kw)    # noqa: E731
+        fused = fuse(t_hits, g_hits, dense_scores, alpha_text=self.alpha_text,
+                     alpha_graph=self.alpha_graph, alpha_dense=self.alpha_dense, top_k=10 ** 9)
         for h in fused:                                   # dense-only ids carry their own meta
             if not h["meta"].get("text") and h["id"] in dense_norm_hits:
                 meta = dict(dense_norm_hits[h["id"]]["meta"])

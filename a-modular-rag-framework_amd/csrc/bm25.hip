@@ -292,3 +292,153 @@ int mrag_bm25_search(mrag_handle h, int n_queries, const int32_t* q_ptr, const i
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// a7 on the device: the fusion arithmetic of HybridRetrievalBackend.run (retrieval_backend.py:336-372) over the
+// three channels' (key, score) lists -- key = the rank of the hit's NORMALISED id among all ids of the call
+// (assigned by the host binding, so ascending key == ascending id, the declared tie order):
+//   per channel  dedupe by key, strictly larger score wins (:336-348)
+//                min-max over the kept scores, all-equal / empty -> 0.0 (:296-301)
+//   union        score = a_t*ts + a_g*gs + a_d*ds, left to right, no contraction (:363)
+//   sort (score desc, key asc), keep top_k (:371-372)
+// One workgroup; the lists are a few hundred entries (pools of 200).  fp64, bit for bit the reference's values.
+// ------------------------------------------------------------------------------------------
+namespace mrag {
+
+constexpr int FUSE_MAX = 4096;   // entries over the three channels
+
+__global__ __launch_bounds__(1024) void fuse_topk_kernel(const int32_t* __restrict__ key, const double* __restrict__ score,
+                                                         const int* __restrict__ chan_ptr /*[4]*/, double a_t, double a_g, double a_d,
+                                                         int top_k, int32_t* __restrict__ out_key, double* __restrict__ out /*[4][top_k]*/,
+                                                         int* __restrict__ out_n, double* __restrict__ work /*[4][n]: norm | fused | kept flag | carrier flag*/) {
+#pragma clang fp contract(off)
+  __shared__ double s_lo[3], s_hi[3];
+  __shared__ int s_any[3], s_cnt;
+  const int tid = threadIdx.x, n = chan_ptr[3];
+  double* norm = work;
+  double* fused = work + n;
+  double* keep = work + 2 * n;     // 1.0 = this entry represents its key in its channel
+  double* carrier = work + 3 * n;  // 1.0 = first kept entry of its key over all channels: carries the fused score
+  if (tid < 3) { s_any[tid] = 0; }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  // 1) dedupe inside each channel: an entry is kept unless another entry of the same channel and key has a
+  //    strictly larger score, or the same score and a smaller index (the first one met keeps the slot)
+  for (int i = tid; i < n; i += blockDim.x) {
+    const int c = i >= chan_ptr[2] ? 2 : (i >= chan_ptr[1] ? 1 : 0);
+    bool k = true;
+    for (int j = chan_ptr[c]; j < chan_ptr[c + 1]; ++j)
+      if (j != i && key[j] == key[i] && (score[j] > score[i] || (score[j] == score[i] && j < i))) { k = false; break; }
+    keep[i] = k ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // 2) per-channel min / max over the kept entries (one thread per channel: the lists are short)
+  if (tid < 3) {
+    double lo = 0.0, hi = 0.0;
+    bool any = false;
+    for (int j = chan_ptr[tid]; j < chan_ptr[tid + 1]; ++j) {
+      if (keep[j] == 0.0) continue;
+      const double v = score[j];
+      if (!any) { lo = hi = v; any = true; }
+      else { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    }
+    s_lo[tid] = lo; s_hi[tid] = hi; s_any[tid] = any ? 1 : 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    const int c = i >= chan_ptr[2] ? 2 : (i >= chan_ptr[1] ? 1 : 0);
+    const double lo = s_lo[c], hi = s_hi[c];
+    norm[i] = (keep[i] != 0.0 && hi > lo) ? (score[i] - lo) / (hi - lo) : 0.0;
+  }
+  __syncthreads();
+  // 3) union: the FIRST kept entry of a key (lowest index over all channels) carries the fused score
+  for (int i = tid; i < n; i += blockDim.x) {
+    fused[i] = 0.0;
+    carrier[i] = 0.0;
+    if (keep[i] == 0.0) continue;
+    double ch[3] = {0.0, 0.0, 0.0};
+    bool first = true;
+    for (int j = 0; j < n; ++j) {
+      if (keep[j] == 0.0 || key[j] != key[i]) continue;
+      if (j < i) { first = false; break; }
+      ch[j >= chan_ptr[2] ? 2 : (j >= chan_ptr[1] ? 1 : 0)] = norm[j];
+    }
+    if (!first) continue;
+    fused[i] = a_t * ch[0] + a_g * ch[1] + a_d * ch[2];
+    carrier[i] = 1.0;
+  }
+  __syncthreads();
+  // 4) rank the carriers by (fused desc, key asc) and write the top_k
+  for (int i = tid; i < n; i += blockDim.x) {
+    if (carrier[i] == 0.0) continue;
+    int rank = 0;
+    for (int j = 0; j < n; ++j)
+      if (carrier[j] != 0.0 && (fused[j] > fused[i] || (fused[j] == fused[i] && key[j] < key[i]))) ++rank;
+    atomicAdd(&s_cnt, 1);
+    if (rank < top_k) {
+      double ch[3] = {0.0, 0.0, 0.0};
+      for (int j = i; j < n; ++j)
+        if (keep[j] != 0.0 && key[j] == key[i]) ch[j >= chan_ptr[2] ? 2 : (j >= chan_ptr[1] ? 1 : 0)] = norm[j];
+      out_key[rank] = key[i];
+      out[rank] = fused[i];
+      out[top_k + rank] = ch[0];
+      out[2 * top_k + rank] = ch[1];
+      out[3 * top_k + rank] = ch[2];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *out_n = min(s_cnt, top_k);
+}
+
+}  // namespace mrag
+
+extern "C" int mrag_fuse_topk(int device, const int32_t* keys, const double* scores, int n_text, int n_graph, int n_dense,
+                              double alpha_text, double alpha_graph, double alpha_dense, int top_k, int32_t* out_keys,
+                              double* out_scores, double* out_text_norm, double* out_graph_norm, double* out_dense_norm,
+                              int* out_n, void* stream_) {
+  using namespace mrag;
+  if (!out_n) return fail(MRAG_ERR_INVALID, "out_n is NULL");
+  *out_n = 0;
+  if (n_text < 0 || n_graph < 0 || n_dense < 0 || top_k < 0) return fail(MRAG_ERR_INVALID, "negative size");
+  const int n = n_text + n_graph + n_dense;
+  if (n > FUSE_MAX) return fail(MRAG_ERR_UNSUPPORTED, "%d fusion entries exceed %d", n, FUSE_MAX);
+  if (n == 0 || top_k == 0) return MRAG_OK;
+  if (!keys || !scores || !out_keys || !out_scores || !out_text_norm || !out_graph_norm || !out_dense_norm)
+    return fail(MRAG_ERR_INVALID, "NULL buffer");
+  for (int i = 0; i < n; ++i)
+    if (!(scores[i] == scores[i])) return fail(MRAG_ERR_INVALID, "NaN score at fusion entry %d", i);
+  MRAG_TRY(use_device(device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const int kk = std::min(top_k, n);
+  // one scratch block: keys | scores | chan_ptr | work[4n] | out_key[kk] | out[4kk] | out_n
+  const size_t o_scores = round_up((int64_t)n * 4, 16), o_ptr = o_scores + (size_t)n * 8, o_work = o_ptr + 16,
+               o_okey = o_work + (size_t)4 * n * 8, o_out = o_okey + round_up((int64_t)kk * 4, 16), o_n = o_out + (size_t)4 * kk * 8,
+               total = o_n + 16;
+  char* d = nullptr;
+  MRAG_HIP(hipMalloc((void**)&d, total));
+  const int ptr[4] = {0, n_text, n_text + n_graph, n};
+  hipError_t e = hipMemcpyAsync(d, keys, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + o_scores, scores, (size_t)n * 8, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + o_ptr, ptr, 16, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(fuse_topk_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)d, (const double*)(d + o_scores),
+                       (const int*)(d + o_ptr), alpha_text, alpha_graph, alpha_dense, kk, (int32_t*)(d + o_okey), (double*)(d + o_out),
+                       (int*)(d + o_n), (double*)(d + o_work));
+    e = hipGetLastError();
+  }
+  int n_out = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_out, d + o_n, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess && n_out > 0) {
+    e = hipMemcpy(out_keys, d + o_okey, (size_t)n_out * 4, hipMemcpyDeviceToHost);
+    double* o = (double*)(d + o_out);
+    if (e == hipSuccess) e = hipMemcpy(out_scores, o, (size_t)n_out * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_text_norm, o + kk, (size_t)n_out * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_graph_norm, o + 2 * kk, (size_t)n_out * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_dense_norm, o + 3 * kk, (size_t)n_out * 8, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(MRAG_ERR_HIP, "fuse_topk failed: %s", hipGetErrorString(e));
+  *out_n = n_out;
+  return MRAG_OK;
+}

@@ -89,6 +89,49 @@ def fuse_channels(text_hits, graph_hits, dense_scores: Dict[str, float], *, alph
     return out[:top_k]
 
 
+def fuse_channels_device(text_hits, graph_hits, dense_scores: Dict[str, float], *, alpha_text: float, alpha_graph: float,
+                         alpha_dense: float, top_k: int, device: int = 0) -> List[Dict[str, Any]]:
+    """:func:`fuse_channels` with the arithmetic on the GPU (``mrag_fuse_topk``): ids are normalised and ranked
+    on the host (a key = the id's position among the call's sorted ids), the dedupe / min-max / weighted sum /
+    sort / truncate of retrieval_backend.py:336-372 run in one launch, and the host re-attaches ids and meta to
+    the ``top_k`` survivors.  Same values bit for bit (fp64, same operation order), same declared tie order."""
+    import ctypes as C
+    import numpy as np
+    from . import _native as N
+    chans = []
+    for hits in (text_hits, graph_hits):
+        ent = []
+        for hit in hits or []:
+            nid, _ = normalize_id(hit)
+            ent.append((nid, float(hit.get("score") or 0.0)))
+        chans.append(ent)
+    chans.append([(nid, float(v)) for nid, v in dense_scores.items()])
+    ids = sorted({nid for ent in chans for nid, _ in ent})
+    if not ids or top_k <= 0:
+        return []
+    key_of = {nid: i for i, nid in enumerate(ids)}
+    keys = np.asarray([key_of[nid] for ent in chans for nid, _ in ent], dtype=np.int32)
+    scores = np.asarray([v for ent in chans for _, v in ent], dtype=np.float64)
+    kk = int(min(top_k, len(ids)))
+    ok, osc = np.empty(kk, dtype=np.int32), np.empty(kk, dtype=np.float64)
+    nt, ng, nd = (np.empty(kk, dtype=np.float64) for _ in range(3))
+    n_out = C.c_int(0)
+    N.check(N.load().mrag_fuse_topk(device, keys.ctypes.data, scores.ctypes.data, len(chans[0]), len(chans[1]), len(chans[2]),
+                                    float(alpha_text), float(alpha_graph), float(alpha_dense), kk, ok.ctypes.data,
+                                    osc.ctypes.data, nt.ctypes.data, ng.ctypes.data, nd.ctypes.data, C.byref(n_out), None))
+    tmap, gmap = dedupe_by_norm_id(text_hits), dedupe_by_norm_id(graph_hits)        # meta merge of the survivors (host dicts)
+    out = []
+    for i in range(n_out.value):
+        nid = ids[int(ok[i])]
+        meta: Dict[str, Any] = {}
+        for src in (tmap, gmap):
+            if nid in src and isinstance(src[nid].get("meta"), dict):
+                meta.update(src[nid]["meta"])
+        meta["score_text_norm"], meta["score_graph_norm"], meta["score_dense_norm"] = float(nt[i]), float(ng[i]), float(nd[i])
+        out.append({"id": nid, "score": float(osc[i]), "meta": meta})
+    return out
+
+
 def normalize_raw_hit(raw: Any, id_keys: Sequence[str] = ID_KEYS, score_keys: Sequence[str] = SCORE_KEYS,
                       meta_key: Optional[str] = "meta") -> Optional[Dict[str, Any]]:
     """retrieval_adapter.py:71-109: first non-None id/score alias, unparsable score -> 0.0,

@@ -201,6 +201,18 @@ int mrag_bm25_destroy(mrag_handle h);
 int mrag_bm25_search(mrag_handle h, int n_queries, const int32_t* q_ptr, const int32_t* q_terms, const double* q_idf,
                      int merge_sum, int k, int64_t* out_docs, double* out_scores, int* out_n, void* stream);
 
+/* a7 on the device: the fusion arithmetic of HybridRetrievalBackend.run (retrieval_backend.py:336-372).
+ * keys / scores hold the text, graph and dense channel entries back to back (n_text, n_graph, n_dense); a key is
+ * the rank of the hit's NORMALISED id (:283-294) among all ids of the call, so ascending key = ascending id.
+ * Per channel: dedupe by key (strictly larger score wins, :336-348), min-max (:296-301); union:
+ * alpha_t*ts + alpha_g*gs + alpha_d*ds (:363); order (score desc, key asc); top_k (:371-372).  fp64, the
+ * reference's values bit for bit.  Outputs (host, length >= min(top_k, entries)): key, fused score and the three
+ * score_*_norm values per kept hit; *out_n = hits written.  At most 4096 entries. */
+int mrag_fuse_topk(int device, const int32_t* keys, const double* scores, int n_text, int n_graph, int n_dense,
+                   double alpha_text, double alpha_graph, double alpha_dense, int top_k, int32_t* out_keys,
+                   double* out_scores, double* out_text_norm, double* out_graph_norm, double* out_dense_norm,
+                   int* out_n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

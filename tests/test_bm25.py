@@ -159,7 +159,7 @@ def test_backend_with_device_bm25_channel(tmp_path):
     docs = tmp_path / "docs.jsonl"
     corpus.write_docs_jsonl(docs, rows)
     corpus.drop_shared("dense-index|"); corpus.drop_shared("bm25-index|")
-    be = DenseRetrievalBackend(Router(), index_path=str(docs), text_channel="bm25", dense_pool_k=100)
+    be = DenseRetrievalBackend(Router(), index_path=str(docs), text_channel="bm25", dense_pool_k=100, fuse_on_device=True)
     req = RetrievalIn(query="gamma river born king", graph_id="", top_k=15, trace_id="t")
     out = be.run(req)
     assert out["diagnostics"]["dense_error"] is None and out["diagnostics"]["text_error"] is None
@@ -174,3 +174,43 @@ def test_backend_with_device_bm25_channel(tmp_path):
     np.testing.assert_allclose([h["score"] for h in out["hits"]], [h["score"] for h in want], rtol=0, atol=1e-4)
     assert len({h["id"] for h in out["hits"]} & {h["id"] for h in want}) >= 13     # BM25 ties cut at the pool edge may differ
     corpus.drop_shared("dense-index|"); corpus.drop_shared("bm25-index|")
+
+
+@pytest.mark.gpu
+def test_fusion_on_device_matches_host_fusion_and_f3(golden_dir):
+    """a7 on the device (mrag_fuse_topk) vs the host fusion (itself bit-exact to F3 = the reference's run()): ids,
+    fused scores and the three score_*_norm values identical, ties included (same declared order)."""
+    from mrag_amd import fusion
+    data = json.loads((golden_dir / "f3_hybrid_run.json").read_text())
+    for c in data["cases"]:
+        kw = c["backend_kwargs"]
+        args = dict(alpha_text=kw["alpha_text"], alpha_graph=kw["alpha_graph"], alpha_dense=kw["alpha_dense"])
+        for top_k in (int(c["req"]["top_k"] or kw["default_top_k"]), 10 ** 9, 1):
+            host = fusion.fuse_channels(c["t_hits_raw"], c["g_hits_raw"], c["dense_scores_raw"], top_k=top_k, **args)
+            dev = fusion.fuse_channels_device(c["t_hits_raw"], c["g_hits_raw"], c["dense_scores_raw"], top_k=top_k, **args)
+            assert dev == host
+        want = c["run_out"]["hits"]
+        dev = fusion.fuse_channels_device(c["t_hits_raw"], c["g_hits_raw"], c["dense_scores_raw"], top_k=len(want), **args)
+        assert [h["score"] for h in dev] == [h["score"] for h in want]
+    # synthetic: duplicate normalised ids inside a channel (strictly larger score wins), exact ties, negative and
+    # all-equal channels, an empty channel, ids present in one / two / three channels
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        def hits(n, lo, dup):
+            out = []
+            for i in range(n):
+                t = int(rng.integers(0, 40)) if dup else i
+                out.append({"id": f"x{i}", "score": float(np.round(rng.normal(lo, 2.0), 1)),
+                            "meta": {"doc": f"T{t}", "sent_id": int(rng.integers(0, 3)), "text": f"s{i}", "m%d" % (i % 3): i}})
+            return out
+        t_hits, g_hits = hits(int(rng.integers(0, 120)), 5.0, True), hits(int(rng.integers(0, 30)), -3.0, trial % 2 == 0)
+        if trial == 3:
+            for h in g_hits:
+                h["score"] = 2.5                                  # all-equal channel -> norms 0.0
+        dense = {f"sent::T{int(rng.integers(0, 60))}::{int(rng.integers(0, 3)) or ''}": float(np.round(rng.uniform(-1, 1), 2))
+                 for _ in range(int(rng.integers(0, 200)))}
+        for top_k in (7, 10 ** 9):
+            host = fusion.fuse_channels(t_hits, g_hits, dense, alpha_text=0.4, alpha_graph=0.2, alpha_dense=0.4, top_k=top_k)
+            dev = fusion.fuse_channels_device(t_hits, g_hits, dense, alpha_text=0.4, alpha_graph=0.2, alpha_dense=0.4, top_k=top_k)
+            assert dev == host, trial
+    assert fusion.fuse_channels_device([], [], {}, alpha_text=1, alpha_graph=1, alpha_dense=1, top_k=5) == []
