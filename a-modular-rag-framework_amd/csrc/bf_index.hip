@@ -722,6 +722,34 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
             if (elane < 16) lds_min_u32(&stat_cur[q0 + nf * 16], f32_ord(x));
           }
           __syncthreads();
+          if constexpr (DESC) if (p.k < K_CERT) {   // descriptor instance only: in the dense instance the extra code costs the K loop registers (+2 % measured)
+            // Sharper bootstrap: the k-th LARGEST of the query's 16 certified maxima (8 lanes x top 2, distinct rows
+            // of this tile) -- k rows reach it, so it certifies like tau0 (which is their 16th largest) and sits
+            // near the true k-th best.  It matters most where a workgroup sees ONE tile (IVF list scan: a 150-row
+            // list leaves lanes with fewer than two valid rows, tau0 = -inf, every row listed and every query sent
+            // through the radix select at the end: 70 % of that kernel).  Rank by counting, 16 work items per
+            // query, register-light (the accumulators are live here).
+#pragma unroll 1
+            for (int wi = tid; wi < min(nq_local, TQ) * 16; wi += NT) {      // (padding queries list nothing: skipped)
+              const int ql = wi >> 4, vi = wi & 15;
+              const int cq = ql & 15, cnf = (ql >> 4) & (NF - 1), cwn = ql / (16 * NF);
+              const uint32_t* col = rm + (cnf * 2) * NT + cwn * 64 + cq;    // + t*NT + ((o>>2)*WN)*64 + (o&3)*16
+              float v16[16];
+#pragma unroll
+              for (int j = 0; j < 16; ++j) v16[j] = __uint_as_float(col[(j & 1) * NT + ((j >> 3) * WN) * 64 + ((j >> 1) & 3) * 16]);   // 16 reads in flight
+              float mine = v16[0];
+#pragma unroll
+              for (int j = 1; j < 16; ++j) mine = (vi == j) ? v16[j] : mine;
+              int rank = 0;
+#pragma unroll
+              for (int j = 0; j < 16; ++j) rank += (v16[j] > mine || (v16[j] == mine && j < vi)) ? 1 : 0;
+              if (rank == p.k - 1 && mine > -INFINITY) {
+                stat_cur[ql] = f32_ord(mine);
+                tau_c[ql] = mine;
+              }
+            }
+            __syncthreads();
+          }
           MRAG_STAMP(11);
 #pragma unroll
           for (int nf = 0; nf < NF; ++nf) thr[nf] = next_below(ord_f32(stat_cur[q0 + nf * 16]));
@@ -914,7 +942,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
       // -- k rows reach it -- and close to the k-th best.  One thread per query sorts the 16 values
       // (bitonic network in registers) and raises tau_c.  Simulated list pushes per (query, split) at
       // k = 10: 231 -> 112 (an exact k-th-best threshold: 88).
-      if (certify && p.k < K_CERT && (ti < 8 || ((ti + 1) & ti) == 0) && ti + 1 < n_tiles) {
+      if (certify && p.k < K_CERT && (!DESC || ti != 0) && (ti < 8 || ((ti + 1) & ti) == 0) && ti + 1 < n_tiles) {   // (descriptor mode, tile 0: done in its bootstrap)
         if (tid < TQ) {
           const int cq = tid & 15, cnf = (tid >> 4) & 3, cwn = tid >> 6;
           float v[16];

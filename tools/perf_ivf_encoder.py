@@ -31,7 +31,10 @@ def ivf(n=625_000, d=768, nlist=4096, nprobe=32, nq=10_000, k=10):
         t0 = time.perf_counter(); sc, ids = ix.search(q, k, nprobe); ts.append(time.perf_counter() - t0)
     bs, bi = bf.search(q, k); torch.cuda.synchronize()
     bi = bi.cpu().numpy()
-    rec = np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, bi)])
+    ids = ids.cpu().numpy() if torch.is_tensor(ids) else ids
+    rec = np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(ids, bi)])
+    t = ix.last_timing()
+    print(f"  list scan {t['scan_ms']:.3f} ms, whole search {t['total_ms']:.3f} ms, {t['n_wg']} workgroups, {t['scanned_rows']} rows")
     print(f"IVF n={n} nlist={nlist} nprobe={nprobe} nq={nq}: train {t_train:.2f}s add {t_add:.2f}s search {min(ts)*1e3:.1f} ms "
           f"({nq/min(ts):.0f} q/s) recall@{k} vs brute force {rec:.4f}", flush=True)
 
