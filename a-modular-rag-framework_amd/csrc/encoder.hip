@@ -287,6 +287,7 @@ __global__ __launch_bounds__(GTHR) void enc_gemm_kernel(const uint16_t* __restri
 // groups and the stores are 8 bytes per lane (the 128 x 128 kernel above stores 2 bytes at a time).
 // Timing-only ablations of the 256 x 256 GEMM (make ENCDIAG=<flags>; results are wrong by design):
 //   1 no epilogue at all | 2 epilogue without the global stores | 4 no GELU | 8 no residual / bias loads
+//   16 only odd workgroups store | 32 only pass 0 stores (is the store phase bound per CU or chip-wide?)
 #ifdef MRAG_ENC_DIAG
 #define ENC_DBG(bit) ((MRAG_ENC_DIAG) & (bit))
 #else
@@ -309,10 +310,9 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
   typedef typename EMfma<DT>::elem elem;
   typedef elem e4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char sm2[];
-  // Every workgroup walks tiles of the same length, so left alone all 256 reach their epilogue together and
-  // the chip alternates between "nobody stores" and a 32 MB store burst that HBM drains while every MFMA pipe
-  // waits.  Start the XCDs (blockIdx % 8: the workgroups that share an L2 stay in step) `stagger` cycles apart,
-  // an eighth of a tile each, so that the bursts of the eight XCDs tile the time axis instead of stacking.
+  // Experiment knob (MRAG_ENC_STAGGER, 0 in production): every workgroup walks tiles of the same length, so all 256
+  // reach their epilogue together; starting the XCDs `stagger` cycles apart was tried to spread the store bursts
+  // and did not help (see run_gemm).
   if (stagger > 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger;
@@ -511,7 +511,11 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
         if (n0 < N) {
           const int token = tm * G2_T + (row >> 5) * 64 + pass * 32 + (row & 31);
           const uint4 val = *(const uint4*)(slab + row * G2_CPITCH + piece * 16);
-          if (!ENC_DBG(2)) *(uint4*)(C + (size_t)token * N + n0) = val;
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 vv = {val.x, val.y, val.z, val.w};
+          if (ENC_DBG(64)) *(uint4*)(C + (size_t)token * N + n0) = val;                      // diag 64: plain (L2-allocating) stores
+          else if (!ENC_DBG(2) && !(ENC_DBG(16) && !(blockIdx.x & 1)) && !(ENC_DBG(32) && pass == 1))
+            __builtin_nontemporal_store(vv, (u32x4*)(C + (size_t)token * N + n0));           // streamed once: do not evict the operand panels from L2
           else if (val.x == 0x12345678u && val.y == 0x9abcdef0u) C[0] = 1;
         }
       }
@@ -792,10 +796,12 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
     int cus = 256;
     { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
     const int nwg = std::min(tm2 * tn2, cus);
-    // XCD start stagger: an eighth of a tile's main loop (~3000 cycles per K step) per XCD, only when every
-    // workgroup has several tiles to walk (the delay is paid once per launch)
     const int per_wg = (tm2 * tn2 + nwg - 1) / nwg;
-    int stagger = (nwg % 8 == 0 && per_wg >= 8) ? (l.K / GK) * 3000 / 8 : 0;
+    // (experiment knob, off by default: starting the XCDs an eighth of a tile apart did NOT shorten the store phase --
+    // 960 -> 970 -> 984 us for the QKV GEMM at 0 / 4500 / 12000 cycles per XCD; what did was streaming the output
+    // with non-temporal stores so that it stops evicting the operand panels from L2, see the epilogue)
+    int stagger = 0;
+    (void)per_wg;
     if (g_stagger_override >= 0) stagger = (nwg % 8 == 0) ? g_stagger_override : 0;
     hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2, stagger);
     MRAG_HIP(hipGetLastError());
