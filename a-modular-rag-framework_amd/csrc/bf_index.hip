@@ -171,9 +171,16 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(lds_off(p)), "v"(x) : "memory");
 }
 
-// cache policy of the corpus-stream LDS-DMA loads ("" = default, " nt" = non-temporal); experiment knob
+// Cache policy of the corpus-stream LDS-DMA loads ("" = default, " nt" = non-temporal), measured on one box:
+//   batch kernel (K2): the five workgroups of an XCD that share a corpus stream rely on each other's lines staying in
+//     L2 for a moment -- nt made it 13 % SLOWER (13.5 -> 15.2 ms at 10 k x 1M): default policy.
+//   streaming kernel (K2s): every corpus byte is read ONCE per launch by ONE workgroup -- nt: 0.270 -> 0.257 ms
+//     (5.69 -> 5.98 TB/s at 1 x 1M x 768).
 #ifndef MRAG_A_POLICY
 #define MRAG_A_POLICY ""
+#endif
+#ifndef MRAG_S_POLICY
+#define MRAG_S_POLICY " nt"
 #endif
 
 // Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG=<flags> build (make DIAG=<flags>):
@@ -528,14 +535,25 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     const char* c0 = base + (size_t)i * chunk_b;
     const char* c1 = c0 + chunk_b;
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
-        : "memory", "scc");
+    if (op == 0) {   // corpus chunks: streamed once per workgroup (cache policy: MRAG_A_POLICY)
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" MRAG_A_POLICY "\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4" MRAG_A_POLICY "\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
+          : "memory", "scc");
+    } else {         // query chunks: re-read for every corpus tile, default policy (L2-resident)
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+          "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff_e), "v"(voff_o), "s"(c0), "s"(c1), "s"(la)
+          : "memory", "scc");
+    }
   };
   auto stage = [&](const char* a, const char* b, int buf) {
     static_assert(CPW == 4, "stage_part covers 4 chunks per operand and wave");
@@ -1137,10 +1155,10 @@ __global__ __launch_bounds__(NTHR, 2) void bf_stream_topk_kernel(StreamParams p)
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+        "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4" MRAG_S_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" MRAG_S_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6" MRAG_S_POLICY "\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7" MRAG_S_POLICY "\n\t"
         "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %8\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
