@@ -1350,11 +1350,22 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
       fill = nb;
     }
     const int off0 = fill + incl - c;
-    for (int i = 0; i < c; ++i) {
-      const uint2 e = p.list[base + i];
-      uint32_t row = e.y;
-      if (p.row_ids) row = (uint32_t)p.row_ids[row];
-      keys[off0 + i] = make_key(e.x, row);
+    // eight entries of the lane's region in flight at a time (written one load per trip, every trip sat out a full
+    // memory round trip: the lists were written by other CUs, so they come from beyond L2 -- 41 us for ONE query's
+    // 256 regions in the online regime)
+    int cmax = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    for (int i0 = 0; i0 < cmax; i0 += 8) {
+      uint2 e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = (i0 + u < c) ? p.list[base + i0 + u] : make_uint2(0u, 0u);
+      if (p.row_ids) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u < c) e[u].y = (uint32_t)p.row_ids[e[u].y];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (i0 + u < c) keys[off0 + i0 + u] = make_key(e[u].x, e[u].y);
     }
     fill += total;
   }
@@ -1366,6 +1377,72 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
     int64_t id = -1;
     if (i < nbest) {
       const uint64_t key = best[i];
+      sc = ord_f32((uint32_t)(key >> 32));
+      id = p.id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+    }
+    p.out_scores[q * k + i] = sc;
+    p.out_ids[q * k + i] = id;
+  }
+}
+
+// K4 for the online regime (a handful of queries x up to 256 splits): four waves per query, each gathers and ranks 64
+// regions on its own (the regions' lists were written by other CUs and come from beyond L2: with ONE wave walking the
+// 256 regions in four dependent batches the merge took 41 us of a 0.30 ms search), then wave 0 merges the 4 x k survivors.
+__global__ __launch_bounds__(256) void bf_merge_par_kernel(MergeParams p) {
+  uint64_t* keys_all = (uint64_t*)smem;               // [4][64 * k] dynamic
+  __shared__ uint64_t best[4][KMAX];
+  __shared__ int nbest[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t q = blockIdx.x;
+  if (q >= p.nq) return;
+  const int t = (int)(q / TQ), ql = (int)(q % TQ);
+  const int k = p.k;
+  uint64_t* keys = keys_all + (size_t)w * 64 * k;
+  const int r = w * 64 + lane;
+  int c = 0;
+  size_t base = 0;
+  if (r < p.S) {
+    const size_t wq = (size_t)(t * p.S + r) * TQ + ql;
+    c = min(p.counts[wq], k);
+    base = wq * QCAP;
+  }
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int fill = __shfl(incl, 63);
+  const int off0 = incl - c;
+  int cmax = c;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+  for (int i0 = 0; i0 < cmax; i0 += 8) {
+    uint2 e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = (i0 + u < c) ? p.list[base + i0 + u] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (i0 + u < c) keys[off0 + i0 + u] = make_key(e[u].x, e[u].y);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int nb = merge_extract(keys, fill, k, best[w], lane);
+  if (lane == 0) nbest[w] = nb;
+  __syncthreads();
+  if (w != 0) return;
+  int tot = 0;
+  for (int v = 0; v < 4; ++v) {
+    for (int i = lane; i < nbest[v]; i += 64) keys_all[tot + i] = best[v][i];
+    tot += nbest[v];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __shared__ uint64_t fin[KMAX];
+  const int nf = merge_extract(keys_all, tot, k, fin, lane);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < k; i += 64) {
+    float sc = -INFINITY;
+    int64_t id = -1;
+    if (i < nf) {
+      const uint64_t key = fin[i];
       sc = ord_f32((uint32_t)(key >> 32));
       id = p.id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)key);
     }
@@ -1504,6 +1581,8 @@ struct BfIndex : Object {
   DevBuf qbuf, lists, counts, stage_in, out_sc, out_id, clock;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool timed = false, want_clock = false;
+  void* q_cleared_buf = nullptr;            // query buffer bookkeeping: rows [q_dirty_rows, q_cleared_rows) are known to be zero
+  int64_t q_cleared_rows = 0, q_dirty_rows = 0;
   ~BfIndex() override {
     if (rows) (void)hipFree(rows);
     qbuf.release(); lists.release(); counts.release(); stage_in.release(); out_sc.release(); out_id.release(); clock.release();
@@ -1685,6 +1764,14 @@ int bf_launch(const BfLaunch& a) {
       mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
       mp.out_scores = a.out_scores + (size_t)g0 * a.k; mp.out_ids = a.out_ids + (size_t)g0 * a.k;
       if (wi) hipLaunchKernelGGL(bf_merge_wide_kernel, dim3((unsigned)gq), dim3(256), 0, stream, mp);
+      else if (S > 64) {
+        static bool par_attr = false;
+        if (!par_attr) {
+          MRAG_HIP(hipFuncSetAttribute((const void*)bf_merge_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * KMAX * 8));
+          par_attr = true;
+        }
+        hipLaunchKernelGGL(bf_merge_par_kernel, dim3((unsigned)gq), dim3(256), (size_t)4 * 64 * a.k * 8, stream, mp);
+      }
       else { mp.cap = merge_lds_entries(S, a.k); hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)gq), dim3(64), (size_t)mp.cap * 8, stream, mp); }
       MRAG_HIP(hipGetLastError());
     }
@@ -1897,7 +1984,16 @@ int mrag_index_search(mrag_handle h, const void* queries, int64_t nq, int q_dtyp
       MRAG_HIP(hipMemcpyAsync(ix->stage_in.p, queries, bytes, hipMemcpyHostToDevice, stream));
       qsrc = ix->stage_in.p;
     }
-    MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, qbytes - (size_t)nq * ix->ld * 2, stream));
+    // rows [nq, nq_pad) must be zero; only rows an earlier (larger) batch wrote need clearing again, so a stream of
+    // equal-sized searches (the online regime: one question per call) pays the fill launch once
+    if (ix->qbuf.p != ix->q_cleared_buf || nq_pad > ix->q_cleared_rows) {
+      MRAG_HIP(hipMemsetAsync(ix->qbuf.p, 0, qbytes, stream));
+      ix->q_cleared_buf = ix->qbuf.p; ix->q_cleared_rows = nq_pad; ix->q_dirty_rows = 0;
+    } else if (ix->q_dirty_rows > nq) {
+      MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, (size_t)(ix->q_dirty_rows - nq) * ix->ld * 2, stream));
+      ix->q_dirty_rows = nq;
+    }
+    ix->q_dirty_rows = std::max<int64_t>(ix->q_dirty_rows, nq);
     MRAG_TRY(launch_prep_rows(qsrc, q_dtype, nq, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                               normalize && ix->metric == MRAG_METRIC_COSINE, stream));
     BfLaunch a;
@@ -1947,6 +2043,7 @@ int mrag_index_score_rows(mrag_handle h, const void* query, int q_dtype, int nor
   MRAG_HIP(hipMemcpyAsync(st + qb, row_ids, (size_t)n * 8, hipMemcpyHostToDevice, stream));
   MRAG_TRY(launch_prep_rows(st, q_dtype, 1, ix->dim, ix->qbuf.p, ix->ld, ix->dtype,
                             normalize && ix->metric == MRAG_METRIC_COSINE, stream));
+  if (ix->qbuf.p == ix->q_cleared_buf) ix->q_dirty_rows = std::max<int64_t>(ix->q_dirty_rows, 1);   // row 0 of the query buffer was written
   hipLaunchKernelGGL(score_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, ix->rows, (const uint16_t*)ix->qbuf.p,
                      ix->ld, ix->dtype == MRAG_BF16 ? 1 : 0, (const int64_t*)(st + qb), n, ix->n, (float*)(st + qb + ib));
   MRAG_HIP(hipGetLastError());
