@@ -1385,78 +1385,130 @@ __global__ __launch_bounds__(64) void bf_merge_kernel(MergeParams p) {
   }
 }
 
-// K4 for the online regime (a handful of queries x up to 256 splits): four waves per query, each gathers and ranks 64
-// regions on its own (the regions' lists were written by other CUs and come from beyond L2: with ONE wave walking the
-// 256 regions in four dependent batches the merge took 41 us of a 0.30 ms search), then wave 0 merges the 4 x k survivors.
-__global__ __launch_bounds__(256) void bf_merge_par_kernel(MergeParams p) {
-  uint64_t* keys_all = (uint64_t*)smem;               // [4][64 * k] dynamic
-  __shared__ uint64_t best[4][KMAX];
-  __shared__ int nbest[4];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// K4s, the merge of the online regime (a handful of queries x up to 256 splits, k <= 256): every split left its k best
+// SORTED, and the global top k draws on average k/S entries from each, so only the heads of the lists are read.  One
+// 256-thread workgroup per query, thread = region: round 1 loads 8 entries of every region into LDS and radix-selects
+// the k-th largest of what is loaded (T); a region whose last loaded entry still reaches T may hold more of the top k
+// and loads 8 more; repeat until no region does.  Then every unloaded entry is below its region's last loaded one,
+// hence below T: the k largest loaded keys ARE the global top k.  Typically one round, 2 048 entries instead of S * k
+// (the one-wave K4 walked 256 regions in four dependent batches: 41 us of a 0.30 ms search; the global-memory radix
+// select K4w took 0.27 ms at k = 200).  A query whose loads would not fit the LDS budget is flagged and left to K4w.
+constexpr int MS_CAP = 12288;          // keys staged in LDS (96 KiB)
+
+// k-th largest of keys[0..n) (n > k, keys unique) as a (shift, prefix) pair: selected <=> (key >> shift) >= prefix.
+// All 256 threads; hist[256] and pick[3] are LDS scratch.
+__device__ __forceinline__ void block_radix_kth(const uint64_t* keys, int n, int k, uint32_t* hist, int* pick, int tid,
+                                                int& shift_out, uint64_t& prefix_out) {
+  const int lane = tid & 63;
+  int need = k, shift = 56;
+  uint64_t prefix = 0ull;
+  for (; shift >= 0; shift -= 8) {
+    hist[tid] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const uint64_t key = keys[i];
+      if (shift == 56 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int hb[4] = {(int)hist[lane * 4], (int)hist[lane * 4 + 1], (int)hist[lane * 4 + 2], (int)hist[lane * 4 + 3]};
+      const int mine = hb[0] + hb[1] + hb[2] + hb[3];
+      int suf = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_down(suf, off);
+        if (lane + off < 64) suf += v;
+      }
+      int cum = suf - mine;
+#pragma unroll
+      for (int b = 3; b >= 0; --b) {
+        if (cum < need && cum + hb[b] >= need) { pick[0] = lane * 4 + b; pick[1] = cum; pick[2] = hb[b]; }
+        cum += hb[b];
+      }
+    }
+    __syncthreads();
+    const int digit = pick[0], above = pick[1], inb = pick[2];
+    need -= above;
+    prefix = (prefix << 8) | (uint64_t)digit;
+    if (inb == need) break;
+  }
+  if (shift < 0) shift = 0;
+  shift_out = shift;
+  prefix_out = prefix;
+}
+
+__global__ __launch_bounds__(256) void bf_merge_sorted_kernel(MergeParams p, int* __restrict__ fallback, int cap) {
+  uint64_t* keys = (uint64_t*)smem;        // [MS_CAP] dynamic
+  __shared__ uint32_t hist[256];
+  __shared__ uint64_t sel[KMAX_WIDE];
+  __shared__ int pick[3];
+  __shared__ int s_total, s_more, s_nsel;
+  const int tid = threadIdx.x;
   const int64_t q = blockIdx.x;
   if (q >= p.nq) return;
   const int t = (int)(q / TQ), ql = (int)(q % TQ);
-  const int k = p.k;
-  uint64_t* keys = keys_all + (size_t)w * 64 * k;
-  const int r = w * 64 + lane;
+  const int k = p.k, S = p.S;
   int c = 0;
   size_t base = 0;
-  if (r < p.S) {
-    const size_t wq = (size_t)(t * p.S + r) * TQ + ql;
+  if (tid < S) {
+    const size_t wq = (size_t)(t * S + tid) * TQ + ql;
     c = min(p.counts[wq], k);
     base = wq * QCAP;
   }
-  int incl = c;
+  if (tid == 0) { s_total = 0; s_nsel = 0; }
+  int loaded = 0, shift = 0;
+  uint64_t last = ~0ull, prefix = 0ull;     // T = (shift, prefix); (0, 0) selects everything
+  bool overflow = false;
+  for (int round = 0; round < 64; ++round) {
+    if (tid == 0) s_more = 0;
+    __syncthreads();
+    const bool want = loaded < c && (last >> shift) >= prefix;
+    const int n_new = want ? min(8, c - loaded) : 0;
+    int slot = 0;
+    if (n_new) { slot = atomicAdd(&s_total, n_new); atomicOr(&s_more, 1); }
+    __syncthreads();
+    if (!s_more) break;
+    if (s_total > cap) { overflow = true; break; }        // (uniform: s_total is read after the barrier)
+    if (n_new) {
+      uint2 e[8];
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  const int fill = __shfl(incl, 63);
-  const int off0 = incl - c;
-  int cmax = c;
+      for (int u = 0; u < 8; ++u) e[u] = u < n_new ? p.list[base + loaded + u] : make_uint2(0u, 0u);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
-  for (int i0 = 0; i0 < cmax; i0 += 8) {
-    uint2 e[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) e[u] = (i0 + u < c) ? p.list[base + i0 + u] : make_uint2(0u, 0u);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) if (i0 + u < c) keys[off0 + i0 + u] = make_key(e[u].x, e[u].y);
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int nb = merge_extract(keys, fill, k, best[w], lane);
-  if (lane == 0) nbest[w] = nb;
-  __syncthreads();
-  if (w != 0) return;
-  int tot = 0;
-  for (int v = 0; v < 4; ++v) {
-    for (int i = lane; i < nbest[v]; i += 64) keys_all[tot + i] = best[v][i];
-    tot += nbest[v];
-  }
-  __builtin_amdgcn_wave_barrier();
-  __shared__ uint64_t fin[KMAX];
-  const int nf = merge_extract(keys_all, tot, k, fin, lane);
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < k; i += 64) {
-    float sc = -INFINITY;
-    int64_t id = -1;
-    if (i < nf) {
-      const uint64_t key = fin[i];
-      sc = ord_f32((uint32_t)(key >> 32));
-      id = p.id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+      for (int u = 0; u < 8; ++u)
+        if (u < n_new) { last = make_key(e[u].x, e[u].y); keys[slot + u] = last; }    // sorted: the last one loaded is the region's smallest so far
+      loaded += n_new;
     }
-    p.out_scores[q * k + i] = sc;
-    p.out_ids[q * k + i] = id;
+    __syncthreads();
+    const int n = s_total;
+    if (n > k) block_radix_kth(keys, n, k, hist, pick, tid, shift, prefix);
+    else { shift = 0; prefix = 0ull; }
   }
+  if (tid == 0) fallback[q] = overflow ? 1 : 0;
+  if (overflow) return;                      // K4w redoes this query from global memory
+  const int n = s_total;
+  for (int i = tid; i < n; i += 256) {
+    const uint64_t key = keys[i];
+    if ((key >> shift) >= prefix) sel[atomicAdd(&s_nsel, 1)] = key;
+  }
+  __syncthreads();
+  const int nsel = s_nsel;                   // = min(n, k)
+  if (tid < nsel) {
+    const uint64_t my = sel[tid];
+    int rank = 0;
+    for (int j = 0; j < nsel; ++j) rank += sel[j] > my ? 1 : 0;
+    p.out_scores[q * k + rank] = ord_f32((uint32_t)(my >> 32));
+    p.out_ids[q * k + rank] = p.id_base + (int64_t)(0xFFFFFFFFu - (uint32_t)my);
+  }
+  for (int i = nsel + tid; i < k; i += 256) { p.out_scores[q * k + i] = -INFINITY; p.out_ids[q * k + i] = -1; }
 }
 
-// K4w (64 < k <= 256, the online regime with the reference's 200-candidate pool): one 256-thread workgroup
+// K4w (fallback of K4s; 64 < k <= 256, the online regime with the reference's 200-candidate pool): one 256-thread workgroup
 // per query selects the k best of the S regions' sorted lists straight from global memory (S*k <= 65 536
 // keys, L2-resident): MSB-first radix select of the k-th key (8 bits per pass over an LDS histogram, stops
 // as soon as the bucket holding the k-th key is needed whole), the k selected keys gathered into LDS and
 // ranked by counting.  Same order as K4: (score desc, row asc); slots past the corpus are (-inf, -1).
-__global__ __launch_bounds__(256) void bf_merge_wide_kernel(MergeParams p) {
+__global__ __launch_bounds__(256) void bf_merge_wide_kernel(MergeParams p, const int* __restrict__ only_flagged) {
+  if (only_flagged && !only_flagged[blockIdx.x]) return;   // K4s handled this query
   __shared__ uint32_t hist[256];
   __shared__ uint64_t sel[KMAX_WIDE];
   __shared__ int cnts[256];
@@ -1731,7 +1783,7 @@ int bf_launch(const BfLaunch& a) {
     return MRAG_OK;
   }
   const int n_ctiles = (int)((a.n_rows + TM - 1) / TM);
-  if (a.k > KMAX || (a.nq <= SQ && n_ctiles >= 8)) {
+  if (a.k > KMAX || (a.nq <= (a.k > 32 ? 8 : SQ) && n_ctiles >= 8)) {
     // ---- online regime: HBM-bound streaming kernel (K2s), one workgroup per CU-sized corpus split ----
     // k <= 64: up to 16 queries per launch; 64 < k <= 256: 8 per launch with 512-entry lists, any nq
     // (larger batches run as consecutive 8-query launches: exact, HBM-bound per launch, not the batch kernel)
@@ -1740,7 +1792,9 @@ int bf_launch(const BfLaunch& a) {
                                    {bf_stream_topk_kernel<MRAG_BF16, 2, 128>, bf_stream_topk_kernel<MRAG_BF16, 1, 512>}};
     static const int slds[2] = {StreamLds<2, 128>::TOTAL, StreamLds<1, 512>::TOTAL};
     static bool s_attr[2][2] = {};
-    const int wi = a.k > KMAX ? 1 : 0;
+    // the 512-entry-list instance also wins for 32 < k <= 64: with 128-entry lists a list of k = 64 is compacted after every
+    // 64-row chunk (1 x 1M x 768: 0.431 ms at k = 64 against 0.332 ms at k = 100 on the wide instance)
+    const int wi = (a.k > 32) ? 1 : 0;
     const int grp = wi ? 8 : SQ;
     if (!s_attr[di][wi]) {
       MRAG_HIP(hipFuncSetAttribute((const void*)sfns[di][wi], hipFuncAttributeMaxDynamicSharedMemorySize, slds[wi]));
@@ -1748,7 +1802,7 @@ int bf_launch(const BfLaunch& a) {
     }
     const int S = std::max(1, std::min(n_ctiles, 256));
     MRAG_TRY(a.lists->ensure((size_t)S * TQ * QCAP * 8));
-    MRAG_TRY(a.counts->ensure((size_t)S * TQ * sizeof(int)));
+    MRAG_TRY(a.counts->ensure(((size_t)S * TQ + 16) * sizeof(int)));   // + the K4s fallback flags of one query group
     for (int64_t g0 = 0; g0 < a.nq; g0 += grp) {
       const int64_t gq = std::min<int64_t>(grp, a.nq - g0);
       StreamParams sp;
@@ -1763,16 +1817,21 @@ int bf_launch(const BfLaunch& a) {
       mp.T = 1; mp.S = S; mp.k = a.k; mp.nq = gq; mp.id_base = a.id_base;
       mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
       mp.out_scores = a.out_scores + (size_t)g0 * a.k; mp.out_ids = a.out_ids + (size_t)g0 * a.k;
-      if (wi) hipLaunchKernelGGL(bf_merge_wide_kernel, dim3((unsigned)gq), dim3(256), 0, stream, mp);
-      else if (S > 64) {
-        static bool par_attr = false;
-        if (!par_attr) {
-          MRAG_HIP(hipFuncSetAttribute((const void*)bf_merge_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * KMAX * 8));
-          par_attr = true;
+      if (wi || S > 64) {
+        // K4s (heads of the sorted lists through LDS) + K4w for the queries it flags (adversarial layouts only)
+        static bool s_attr2 = false;
+        if (!s_attr2) {
+          MRAG_HIP(hipFuncSetAttribute((const void*)bf_merge_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MS_CAP * 8));
+          s_attr2 = true;
         }
-        hipLaunchKernelGGL(bf_merge_par_kernel, dim3((unsigned)gq), dim3(256), (size_t)4 * 64 * a.k * 8, stream, mp);
+        int* flags = (int*)a.counts->p + (size_t)S * TQ;       // 16 ints behind the per-region counts
+        static const int ms_cap = [] { const char* e = getenv("MRAG_K4S_CAP"); return e ? std::max(0, std::min(atoi(e), MS_CAP)) : MS_CAP; }();   // test knob: 0 sends every query to K4w
+        hipLaunchKernelGGL(bf_merge_sorted_kernel, dim3((unsigned)gq), dim3(256), (size_t)MS_CAP * 8, stream, mp, flags, ms_cap);
+        hipLaunchKernelGGL(bf_merge_wide_kernel, dim3((unsigned)gq), dim3(256), 0, stream, mp, (const int*)flags);
+      } else {
+        mp.cap = merge_lds_entries(S, a.k);
+        hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)gq), dim3(64), (size_t)mp.cap * 8, stream, mp);
       }
-      else { mp.cap = merge_lds_entries(S, a.k); hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)gq), dim3(64), (size_t)mp.cap * 8, stream, mp); }
       MRAG_HIP(hipGetLastError());
     }
     return MRAG_OK;

@@ -191,3 +191,31 @@ def test_backend_pool_200_cold_warm_and_reranker_lookup(tmp_path):
     assert Prov.calls == [1, 1] and list(got) == list(ref)
     assert max(abs(got[k] - ref[k]) for k in ref) < 1e-3            # fp16 storage of the cached rows
     corpus.drop_shared("dense-index|")
+
+
+def test_online_merge_fallback_path_matches(monkeypatch):
+    """The online merge reads only the heads of the per-split sorted lists (K4s) and leaves queries whose loads
+    would not fit its LDS budget to the global-memory radix select (K4w).  MRAG_K4S_CAP=0 (read once per process:
+    a subprocess) sends every query down the fallback; both must give the oracle's answer."""
+    import subprocess, sys, os
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import numpy as np
+from mrag_amd.index import DenseIndex
+from oracle import dense_search as ds
+c16 = ds.normalize_round(ds.make_gaussian(40000, 64, 1)); q16 = ds.normalize_round(ds.make_gaussian(5, 64, 2))
+ix = DenseIndex(64); ix.add(c16, normalize=False)
+for k in (10, 64, 200):
+    sc, ids = ix.search(q16, k, normalize=False)
+    rv, ri = ds.brute_force_topk(q16, c16, k)
+    assert np.allclose(sc, rv, rtol=0, atol=1e-5) and ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)[1] == 0, k
+print("ok")
+''' % str(root)
+    for cap in ("0", "64", None):
+        env = dict(os.environ)
+        if cap is not None:
+            env["MRAG_K4S_CAP"] = cap
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (cap, r.stdout[-500:], r.stderr[-1500:])
