@@ -269,11 +269,17 @@ def main():
     sh.index.measure_clock(False)
 
     # the online regime (one query per call = the reference's own usage): K2s, HBM-bound
-    online_ms = []
+    online_ms, online_search_ms, online_pool_ms = [], [], []
     for i in range(8):
         sh.index.search(queries[:1], k)
         if i > 1:
-            online_ms.append(sh.index.last_timing_ms()[0])
+            g_ms, t_ms = sh.index.last_timing_ms()
+            online_ms.append(g_ms)
+            online_search_ms.append(t_ms)
+    for i in range(6):                      # the reference's dense pool: 200 candidates per question (settings.yaml:101-102)
+        sh.index.search(queries[:1], 200)
+        if i > 1:
+            online_pool_ms.append(sh.index.last_timing_ms()[1])
     fence()
 
     out = None
@@ -315,7 +321,10 @@ def main():
         on_bytes = (sh.hi - sh.lo) * d * 2.0 + d * 2.0
         out["online_roofline"] = {"bound": "hbm", "kernel": "bf_stream_topk_kernel", "workload": "1 query x this rank's rows, k=10",
                                   "kernel_ms": on_ms, "achieved": on_bytes / (on_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": on_bytes / (on_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": on_bytes}
+                                  "frac": on_bytes / (on_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": on_bytes,
+                                  "search_ms": float(np.median(online_search_ms)),
+                                  "search_ms_k200": float(np.median(online_pool_ms)),
+                                  "note": "search_ms = K1 + streaming kernel + merge on the device, one question; k200 = the reference's 200-candidate pool"}
         # HBM-side traffic of K2 comes from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; profiles/r*_pmc_traffic.json, tools/profile_round.sh)
         pmcs = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))
