@@ -529,9 +529,12 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
 // ------------------------------------------------------------------ attention
 // QKV [M_pad][3H] (q | k | v per token), mask [B][S] (1 = token), out [M_pad][H].
 // grid = B * heads * ceil(S/64); 256 threads: wave w owns query rows 16w..16w+15 of the block.
-template <int DT, int DH>
-__global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                            uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
+// NW waves = 16 * NW query rows per workgroup: 8 waves (128 rows) when S > 64, so that a 128-token passage stages its
+// K / V blocks once instead of once per 64-row half (attention 0.59 -> see DESIGN); 4 waves for shorter sequences.
+template <int DT, int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                                uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
+  constexpr int QB = 16 * NW, NT_ = 64 * NW;
   typedef typename EMfma<DT>::frag frag;
   typedef typename EMfma<DT>::elem elem;
   constexpr int KB = 64;                       // keys per block
@@ -539,16 +542,16 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __re
   constexpr int ND = DH / 16;                  // 16-column groups of the output
   __shared__ __attribute__((aligned(16))) elem sK[KB][DH + 8];       // [key][dh]   (+8: 16-B pad against bank conflicts)
   __shared__ __attribute__((aligned(16))) elem sVt[DH][KB + 8];      // [dh][key]
-  __shared__ __attribute__((aligned(16))) elem sP[4][16][KB + 8];    // per wave [q row][key]
+  __shared__ __attribute__((aligned(16))) elem sP[NW][16][KB + 8];   // per wave [q row][key]
   __shared__ float sBias[KB];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nqb = (S + 63) / 64;
+  const int nqb = (S + QB - 1) / QB;
   const int qb = blockIdx.x % nqb;
   const int hh = (blockIdx.x / nqb) % heads;
   const int bb = blockIdx.x / (nqb * heads);
   const size_t ld = (size_t)3 * H;
   const uint16_t* base = qkv + (size_t)bb * S * ld;
-  const int q_row = qb * 64 + w * 16 + (lane & 15);           // A operand row of this lane
+  const int q_row = qb * QB + w * 16 + (lane & 15);           // A operand row of this lane
   // Q fragments: lane holds Q[q_row][k = 32*ks + 8*(lane>>4) + j]
   frag qf[NK];
 #pragma unroll
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __re
   for (int k0 = 0; k0 < S; k0 += KB) {
     __syncthreads();
     // stage K (row-major) and V (transposed) of this key block; 256 threads x 16 B = one 64 x 32 slab per pass
-    for (int e = tid; e < KB * (DH / 8); e += 256) {
+    for (int e = tid; e < KB * (DH / 8); e += NT_) {
       const int key = e / (DH / 8), c = e % (DH / 8);
       frag kv, vv;
 #pragma unroll
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __re
       }
     }
   }
-  // out[row][hh*DH + 16*d + (lane&15)], row = qb*64 + w*16 + (lane>>4)*4 + r.  The wave's 16 x DH block goes
+  // out[row][hh*DH + 16*d + (lane&15)], row = qb*QB + w*16 + (lane>>4)*4 + r.  The wave's 16 x DH block goes
   // through its (now idle) P slab so that it leaves as 16-byte pieces of whole DH-wide rows instead of
   // sixteen 2-byte stores per lane.
   __builtin_amdgcn_wave_barrier();
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const uint16_t* __re
   constexpr int PIECES = DH / 8;                 // 16-byte pieces per row
   for (int e = lane; e < 16 * PIECES; e += 64) {
     const int rr = e / PIECES, pc = e % PIECES;
-    const int row = qb * 64 + w * 16 + rr;
+    const int row = qb * QB + w * 16 + rr;
     if (row < S) *(frag*)&out[((size_t)bb * S + row) * H + hh * DH + pc * 8] = *(const frag*)&sP[w][rr][pc * 8];
   }
 }
@@ -839,13 +842,17 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
   MRAG_HIP(hipGetLastError());
   const int dh = H / c.heads;
   const float scale = 1.0f / sqrtf((float)dh);
-  const dim3 agrid((unsigned)(B * c.heads * ((S + 63) / 64)));
+  const bool wide_attn = S > 64;
+  const dim3 agrid((unsigned)(B * c.heads * (wide_attn ? (S + 127) / 128 : 1)));
   for (int li = 0; li < c.layers; ++li) {
     Layer& L = e->layers[li];
     MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, M_pad, EPI_BIAS, stream));
-    if (dh == 32) hipLaunchKernelGGL((enc_attention_kernel<DT, 32>), agrid, dim3(256), 0, stream, qkv, (const int32_t*)e->mask.p, ctx, B, S, H, c.heads, scale);
-    else if (dh == 64) hipLaunchKernelGGL((enc_attention_kernel<DT, 64>), agrid, dim3(256), 0, stream, qkv, (const int32_t*)e->mask.p, ctx, B, S, H, c.heads, scale);
-    else return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
+    const int32_t* am = (const int32_t*)e->mask.p;
+    if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
+    if (dh == 32 && wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+    else if (dh == 32) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+    else if (wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+    else hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     MRAG_HIP(hipGetLastError());
     MRAG_TRY(run_gemm<DT>(ctx, L.attn_out, x, y, M_pad, EPI_RESID, stream));                    // y = ctx Wo + b + x
     launch_ln<elem>((const elem*)y, M, H, L.ln1_g, L.ln1_b, c.layer_norm_eps, (elem*)x, tok_grid, tok_block, stream);
