@@ -313,9 +313,11 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
   // Experiment knob (MRAG_ENC_STAGGER, 0 in production): every workgroup walks tiles of the same length, so all 256
   // reach their epilogue together; starting the XCDs `stagger` cycles apart was tried to spread the store bursts
   // and did not help (see run_gemm).
-  if (stagger > 0) {
+  if (stagger != 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger;
+    // > 0: XCDs apart; < 0: the workgroups of one XCD apart (blockIdx >> 3 = position inside the XCD)
+    const unsigned long long wait = stagger > 0 ? (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger
+                                                : (unsigned long long)(blockIdx.x >> 3) * (unsigned long long)(-stagger);
     while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
   }
   const int tid = threadIdx.x, lane = tid & 63;
@@ -781,7 +783,7 @@ static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hi
 }
 
 // development switch (MRAG_ENC_GEMM128=1): force the 128 x 128 kernel, for A/B timing
-static const int g_stagger_override = [] { const char* e = getenv("MRAG_ENC_STAGGER"); return e ? atoi(e) : -1; }();   // experiment knob
+static const int g_stagger_override = [] { const char* e = getenv("MRAG_ENC_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob
 static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM128"); return e && atoi(e) != 0; }();
 
 template <int DT>
@@ -805,7 +807,7 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
     // with non-temporal stores so that it stops evicting the operand panels from L2, see the epilogue)
     int stagger = 0;
     (void)per_wg;
-    if (g_stagger_override >= 0) stagger = (nwg % 8 == 0) ? g_stagger_override : 0;
+    if (g_stagger_override != 0) stagger = (nwg % 8 == 0) ? g_stagger_override : 0;
     hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2, stagger);
     MRAG_HIP(hipGetLastError());
     return MRAG_OK;
