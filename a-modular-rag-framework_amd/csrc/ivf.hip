@@ -36,13 +36,15 @@ struct IvfIndex : Object {
   std::vector<int> list_tile_lo, list_count;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
+  DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
+  bool last_scores_path = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | list scan begin | list scan end | search end
   bool timed = false;
   int last_n_wg = 0;
   ~IvfIndex() override {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
-    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan}) b->release();
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc}) b->release();
   }
 };
 
@@ -123,15 +125,79 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ 
 
 __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
                                    const int* __restrict__ list_count, const int* __restrict__ wg_first,
-                                   int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc) {
+                                   int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc, int qshift) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npairs) return;
   const int64_t l = probes[i];
   if (l < 0 || list_count[l] == 0) { ploc[i] = make_int2(-1, 0); return; }
   const int pos = atomicAdd(&cursor[l], 1);
-  const int wgi = wg_first[l] + (pos >> 8), slot = pos & 255;
-  gq[(size_t)wgi * 256 + slot] = i / nprobe;
+  const int wgi = wg_first[l] + (pos >> qshift), slot = pos & ((1 << qshift) - 1);   // 2^qshift queries per workgroup
+  gq[((size_t)wgi << qshift) + slot] = i / nprobe;
   ploc[i] = make_int2(wgi, slot);
+}
+
+// Plan of the "score segments + select" regime (ivf_scan.hip): workgroups of <= 128 queries, each list's scores
+// as one block S[query slot of the list][pitch = list rows rounded to 4]; out[0] = workgroups, out[1..2] = floats.
+__global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
+                                                               const int* __restrict__ list_tile_lo, int nlist,
+                                                               int* __restrict__ wg_first, int* __restrict__ cursor,
+                                                               int* __restrict__ desc, int desc_cap, int* __restrict__ out) {
+  __shared__ int part[1024];
+  __shared__ long long fpart[1024];
+  __shared__ int carry;
+  __shared__ long long fcarry;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry = 0; fcarry = 0; }
+  __syncthreads();
+  for (int base = 0; base < nlist; base += 1024) {
+    const int l = base + tid;
+    const int cnt = l < nlist ? lcount[l] : 0;
+    const int lc = l < nlist ? list_count[l] : 0;
+    const int nt = (cnt + IVFS_QUERIES - 1) / IVFS_QUERIES;
+    const int pitch = (lc + 3) & ~3;
+    const long long fl = (long long)cnt * pitch;
+    part[tid] = nt;
+    fpart[tid] = fl;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // inclusive scans (Hillis-Steele)
+      const int v = tid >= off ? part[tid - off] : 0;
+      const long long fv = tid >= off ? fpart[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      fpart[tid] += fv;
+      __syncthreads();
+    }
+    const int first = carry + part[tid] - nt;
+    const long long foff = fcarry + fpart[tid] - fl;
+    if (l < nlist) {
+      wg_first[l] = first;
+      cursor[l] = 0;
+      const int tlo = list_tile_lo[l];
+      for (int c = 0; c < nt; ++c) {
+        const int wgi = first + c;
+        if (wgi < desc_cap) {
+          int* d = desc + (size_t)wgi * IVFS_DESC_WORDS;
+          const long long so = foff + (long long)c * IVFS_QUERIES * pitch;
+          d[0] = wgi * IVFS_QUERIES;
+          d[1] = min(IVFS_QUERIES, cnt - c * IVFS_QUERIES);
+          d[2] = tlo * 256;
+          d[3] = lc;
+          d[4] = 0;
+          d[5] = (int)(unsigned)(so & 0xFFFFFFFFll);
+          d[6] = (int)(so >> 32);
+          d[7] = pitch;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) { carry += part[1023]; fcarry += fpart[1023]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out[0] = carry;
+    out[1] = (int)(unsigned)(fcarry & 0xFFFFFFFFll);
+    out[2] = (int)(fcarry >> 32);
+  }
 }
 
 // nprobe == nlist: every query probes every list (the exhaustive limit, == brute force)
@@ -485,10 +551,19 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   MRAG_TRY(ivf_prepare(ix, queries, nq, q_dtype, normalize, queries_is_device, (uint16_t*)ix->qbuf.p, stream));
   MRAG_TRY(ix->tmp_id.ensure((size_t)nq * nprobe * 8));
   MRAG_TRY(ix->tmp_sc.ensure((size_t)nq * nprobe * 4));
+  // The list scan (and the probe selection before it) runs as "score segments + select" (ivf_scan.hip) whenever the
+  // fp32 segments of this search fit the score buffer; otherwise (exhaustive probing of a big index) as the fused
+  // GEMM + top-k kernel in descriptor mode.  MRAG_IVF_SCORES_MB = 0 forces the fused path (tests).
+  static const int64_t scores_cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 4096) << 20; }();
   if (nprobe == ix->nlist) {
     const int64_t np_ = nq * nprobe;
     hipLaunchKernelGGL(ivf_all_lists_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, stream, (int64_t*)ix->tmp_id.p, np_, ix->nlist);
     MRAG_HIP(hipGetLastError());
+  } else if (round_up(nq, IVFS_QUERIES) * (int64_t)((ix->nlist + 3) & ~3) * 4 <= scores_cap) {
+    MRAG_TRY(ix->sdesc.ensure((size_t)ivfs_dense_n_desc(nq, ix->nlist) * IVFS_DESC_WORDS * 4));
+    MRAG_TRY(ix->scores.ensure((size_t)(round_up(nq, IVFS_QUERIES) * (int64_t)((ix->nlist + 3) & ~3) * 4)));
+    MRAG_TRY(ivfs_dense_topk(ix->cen, ix->nlist, (const uint16_t*)ix->qbuf.p, nq, ix->ld, ix->dtype, nprobe, (int*)ix->sdesc.p,
+                             (float*)ix->scores.p, (float*)ix->tmp_sc.p, (int64_t*)ix->tmp_id.p, stream));
   } else {
     BfLaunch a;
     a.corpus = ix->cen; a.queries = (const uint16_t*)ix->qbuf.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = nprobe;
@@ -497,11 +572,11 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
     MRAG_TRY(bf_launch(a));
   }
-  // 2) device: list -> the queries that probe it, cut into workgroups of <= 256 queries (kernels above).
-  //    Only the workgroup count comes back to the host (4 bytes) -- it sizes the gather and the grid.
+  // 2) device: list -> the queries that probe it, cut into workgroups of <= 128 (score segments) or <= 256 (fused
+  //    kernel) queries.  Only the workgroup count and the size of the segments come back to the host (12 bytes).
   const size_t npairs = (size_t)nq * nprobe;
   const int nl = ix->nlist;
-  const int64_t wg_bound = (int64_t)std::min<size_t>((size_t)nl, npairs) + (int64_t)(npairs / 256) + 1;
+  const int64_t wg_bound = (int64_t)std::min<size_t>((size_t)nl, npairs) + (int64_t)(npairs / IVFS_QUERIES) + 1;   // (covers the 256-query plan too)
   MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
   int* d_lcount = (int*)ix->plan.p;
   int* d_wg_first = d_lcount + nl;
@@ -515,24 +590,49 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
   hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
                      (const int*)ix->d_list_count.p, d_lcount);
-  hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
-                     (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
-  hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
-                     (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p);
-  MRAG_HIP(hipGetLastError());
-  int n_wg = 0;
-  MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
-  MRAG_HIP(hipStreamSynchronize(stream));
-  if (n_wg < 0 || n_wg > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", n_wg, (long long)wg_bound);
-  // 3) gather queries per workgroup, scan the lists, merge
-  if (n_wg) {
-    MRAG_TRY(ix->qg.ensure((size_t)n_wg * 256 * ix->ld * 2));
-    const int64_t ng = (int64_t)n_wg * 256;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)ix->qbuf.p,
-                       (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p, 0);
+  bool use_scores = scores_cap > 0 && nprobe <= 256;   // (the select kernel holds <= 256 segments per query; exhaustive probing takes the fused path)
+  int plan_out[3] = {0, 0, 0};
+  if (use_scores) {
+    hipLaunchKernelGGL(ivf_plan_scores_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
+                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
     MRAG_HIP(hipGetLastError());
+    MRAG_HIP(hipMemcpyAsync(plan_out, d_nwg, 12, hipMemcpyDeviceToHost, stream));
+    MRAG_HIP(hipStreamSynchronize(stream));
+    const int64_t floats = (int64_t)(uint32_t)plan_out[1] | ((int64_t)plan_out[2] << 32);
+    if (plan_out[0] < 0 || plan_out[0] > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", plan_out[0], (long long)wg_bound);
+    if (floats * 4 > scores_cap) use_scores = false;
+    else MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>(floats, 4) * 4));
   }
-  {
+  int n_wg = 0;
+  if (use_scores) {
+    n_wg = plan_out[0];
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
+                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 7);
+    MRAG_HIP(hipGetLastError());
+    // 3) scores of every (query, probed list) pair, then the k best per query
+    MRAG_HIP(hipEventRecord(ix->ev[1], stream));
+    MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, n_wg,
+                       (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
+    MRAG_TRY(ivfs_select_lists((const float*)ix->scores.p, (const int*)ix->desc.p, ix->ploc.p, nprobe, nq, k, ix->row_ids, ix->id_base,
+                               d_sc, d_id, stream));
+    MRAG_HIP(hipEventRecord(ix->ev[2], stream));
+  } else {
+    hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
+                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
+    hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
+                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8);
+    MRAG_HIP(hipGetLastError());
+    MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
+    MRAG_HIP(hipStreamSynchronize(stream));
+    if (n_wg < 0 || n_wg > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", n_wg, (long long)wg_bound);
+    // 3) gather queries per workgroup, scan the lists, merge
+    if (n_wg) {
+      MRAG_TRY(ix->qg.ensure((size_t)n_wg * 256 * ix->ld * 2));
+      const int64_t ng = (int64_t)n_wg * 256;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, (const uint16_t*)ix->qbuf.p,
+                         (const int64_t*)ix->gq.p, ng, ix->ld, (uint16_t*)ix->qg.p, 0);
+      MRAG_HIP(hipGetLastError());
+    }
     BfLaunch a;
     a.corpus = ix->sorted; a.queries = (const uint16_t*)ix->qg.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = k;
     a.nq = nq;
@@ -545,6 +645,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     a.ev_k2_begin = ix->ev[1]; a.ev_k2_end = ix->ev[2];
     MRAG_TRY(bf_launch(a));
   }
+  ix->last_scores_path = use_scores;
   MRAG_HIP(hipEventRecord(ix->ev[3], stream));
   ix->last_n_wg = n_wg;
   ix->timed = true;
@@ -573,7 +674,8 @@ int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms,
     std::vector<int> d((size_t)ix->last_n_wg * 8);
     if (ix->last_n_wg) MRAG_HIP(hipMemcpy(d.data(), ix->desc.p, d.size() * 4, hipMemcpyDeviceToHost));
     int64_t rows = 0;
-    for (int w = 0; w < ix->last_n_wg; ++w) rows += (int64_t)d[(size_t)w * 8 + 4] - (int64_t)d[(size_t)w * 8 + 2] * 256;
+    for (int w = 0; w < ix->last_n_wg; ++w)
+      rows += ix->last_scores_path ? (int64_t)d[(size_t)w * 8 + 3] : (int64_t)d[(size_t)w * 8 + 4] - (int64_t)d[(size_t)w * 8 + 2] * 256;
     *out_scanned_rows = rows;
   }
   return MRAG_OK;

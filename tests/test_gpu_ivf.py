@@ -87,3 +87,78 @@ def test_ivf_edge_cases():
     ix.add(rows, normalize=False)
     sc, ids = ix.search(rows[:2], 10, 4, normalize=False)  # k > n
     assert (ids[:, 7:] == -1).all() and (ids[:, 0] == [0, 1]).all()
+
+
+def _ivf_with(c16, cen):
+    from mrag_amd.index import IVFFlatIndex
+    ix = IVFFlatIndex(c16.shape[1], cen.shape[0])
+    ix.set_centroids(cen, normalize=False)
+    ix.add(c16, normalize=False)
+    return ix
+
+
+def test_select_ties_and_large_candidate_sets():
+    """The score-segment regime's per-query selection (csrc/ivf_scan.hip): order is (score desc, original row asc) also
+    when hundreds of rows tie on the k-th score (shortlist overflow -> serial path) and when a query has more
+    candidates than the register-resident fast path holds (> 8192 -> serial path)."""
+    d, nlist = 64, 8
+    rng = np.random.default_rng(5)
+    base = ds.normalize_round(ds.make_gaussian(3000, d, 21))
+    dup = np.repeat(base[:3], 1200, axis=0)                    # 3 rows x 1200 identical copies: more ties than the shortlist holds
+    dup2 = np.repeat(base[3:6], 300, axis=0)                   # 3 rows x 300: ties ranked inside the shortlist
+    c16 = np.concatenate([base, dup, dup2], axis=0)
+    perm = rng.permutation(len(c16))
+    c16 = c16[perm]
+    cen = ds.kmeans_spherical(c16, nlist, 3, seed=1)
+    ix = _ivf_with(c16, cen)
+    q16 = np.concatenate([base[:6], ds.normalize_round(ds.make_gaussian(26, d, 22))], axis=0)
+    for k in (1, 10, 64):
+        sc, ids = ix.search(q16, k, nlist // 2, normalize=False)
+        rv, ri = ds.ivf_search(q16, c16, cen, ix.assignments().astype(np.int64), nlist // 2, k)
+        np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+        # the duplicated rows: the query IS the row, its copies score exactly alike -> lowest original rows first
+        for qi in range(6):
+            copies = np.sort(np.nonzero((c16 == q16[qi]).all(axis=1))[0])
+            assert (ids[qi] == copies[:k]).all(), (k, qi, ids[qi][:8], copies[:8])
+        strict, bad = ds.gap_aware_id_match(ids[6:], sc[6:], ri[6:], rv[6:], tol=1e-5)
+        assert bad == 0
+    # > 8192 candidates per query: 40 000 rows in 4 lists, all probed through the selection kernel (nprobe < nlist)
+    big = ds.normalize_round(ds.make_gaussian(40000, d, 23))
+    cen5 = ds.kmeans_spherical(big, 5, 3, seed=2)
+    ix5 = _ivf_with(big, cen5)
+    qs = ds.normalize_round(ds.make_gaussian(16, d, 24))
+    sc, ids = ix5.search(qs, 10, 4, normalize=False)
+    rv, ri = ds.ivf_search(qs, big, cen5, ix5.assignments().astype(np.int64), 4, 10)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
+    assert bad == 0
+
+
+def test_fused_regime_gives_the_same_answer():
+    """MRAG_IVF_SCORES_MB=0 forces the fused GEMM + top-k kernel in descriptor mode (the regime kept for searches whose
+    score segments would not fit): same scores bit for bit, same ids."""
+    import os, subprocess, sys, tempfile, textwrap
+    code = textwrap.dedent('''
+        import sys, numpy as np
+        sys.path.insert(0, ".")
+        from oracle import dense_search as ds
+        from mrag_amd.index import IVFFlatIndex
+        rows, qs = ds.make_clustered(30000, 500, 128, 31, n_centroids=64)
+        c16, q16 = ds.normalize_round(rows), ds.normalize_round(qs)
+        cen = ds.kmeans_spherical(c16, 96, 3, seed=4)
+        ix = IVFFlatIndex(128, 96); ix.set_centroids(cen, normalize=False); ix.add(c16, normalize=False)
+        out = {}
+        for k, nprobe in ((10, 8), (64, 16), (3, 96)):
+            sc, ids = ix.search(q16, k, nprobe, normalize=False)
+            out["s%d_%d" % (k, nprobe)] = sc; out["i%d_%d" % (k, nprobe)] = ids
+        np.savez(sys.argv[1], **out)
+    ''')
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for mode, env in (("scores", {}), ("fused", {"MRAG_IVF_SCORES_MB": "0"})):
+            path = os.path.join(td, mode + ".npz")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, cwd=os.path.dirname(os.path.dirname(__file__)))
+            res[mode] = np.load(path)
+        for key in res["scores"].files:
+            a, b = res["scores"][key], res["fused"][key]
+            assert np.array_equal(a, b), key
