@@ -34,6 +34,7 @@ struct IvfIndex : Object {
   int64_t* row_ids = nullptr;     // [n_sorted] original row or -1
   int64_t n_sorted = 0;
   std::vector<int> list_tile_lo, list_count;
+  int max_list_rows = 0;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
   DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
@@ -324,6 +325,7 @@ static int ivf_finalize(IvfIndex* ix, hipStream_t stream) {
   MRAG_HIP(hipMemcpyAsync(ix->d_list_tile_lo.p, ix->list_tile_lo.data(), (size_t)ix->nlist * 4, hipMemcpyHostToDevice, stream));
   MRAG_HIP(hipStreamSynchronize(stream));
   ix->n_sorted = ns;
+  ix->max_list_rows = ix->list_count.empty() ? 0 : *std::max_element(ix->list_count.begin(), ix->list_count.end());
   ix->dirty = false;
   return MRAG_OK;
 }
@@ -547,7 +549,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   // 1) queries -> storage dtype; probe lists
   const int64_t nq_pad = bf_round_rows(nq) + 16;   // + 16 zero rows: the streaming kernel's last 8-query group reads a 16-row block
   MRAG_TRY(ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2));
-  MRAG_HIP(hipMemsetAsync(ix->qbuf.p, 0, (size_t)nq_pad * ix->ld * 2, stream));
+  MRAG_HIP(hipMemsetAsync((char*)ix->qbuf.p + (size_t)nq * ix->ld * 2, 0, (size_t)(nq_pad - nq) * ix->ld * 2, stream));   // (rows < nq: written whole by the prepare kernel)
   MRAG_TRY(ivf_prepare(ix, queries, nq, q_dtype, normalize, queries_is_device, (uint16_t*)ix->qbuf.p, stream));
   MRAG_TRY(ix->tmp_id.ensure((size_t)nq * nprobe * 8));
   MRAG_TRY(ix->tmp_sc.ensure((size_t)nq * nprobe * 4));
@@ -586,37 +588,51 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
   MRAG_TRY(ix->ploc.ensure(npairs * 8));
   MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
-  MRAG_HIP(hipMemsetAsync(ix->gq.p, 0xFF, (size_t)wg_bound * 256 * 8, stream));
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
   hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
                      (const int*)ix->d_list_count.p, d_lcount);
   bool use_scores = scores_cap > 0 && nprobe <= 256;   // (the select kernel holds <= 256 segments per query; exhaustive probing takes the fused path)
+  // Score floats of this search: known exactly only on the device (sum over the probed lists of queries x rows).  When
+  // even the bound "every pair probes the longest list" fits the buffer, nothing comes back to the host at all: the
+  // scan is launched over the BOUND of the workgroup count and reads the real one from device memory.
+  const int64_t max_pitch = ((int64_t)ix->max_list_rows + 3) & ~3ll;
+  const bool no_sync = use_scores && (int64_t)npairs * max_pitch * 4 <= scores_cap;
   int plan_out[3] = {0, 0, 0};
   if (use_scores) {
     hipLaunchKernelGGL(ivf_plan_scores_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
                        (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
     MRAG_HIP(hipGetLastError());
-    MRAG_HIP(hipMemcpyAsync(plan_out, d_nwg, 12, hipMemcpyDeviceToHost, stream));
-    MRAG_HIP(hipStreamSynchronize(stream));
-    const int64_t floats = (int64_t)(uint32_t)plan_out[1] | ((int64_t)plan_out[2] << 32);
-    if (plan_out[0] < 0 || plan_out[0] > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", plan_out[0], (long long)wg_bound);
-    if (floats * 4 > scores_cap) use_scores = false;
-    else MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>(floats, 4) * 4));
+    if (no_sync) {
+      MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>((int64_t)npairs * max_pitch, 4) * 4));
+    } else {
+      MRAG_HIP(hipMemcpyAsync(plan_out, d_nwg, 12, hipMemcpyDeviceToHost, stream));
+      MRAG_HIP(hipStreamSynchronize(stream));
+      const int64_t floats = (int64_t)(uint32_t)plan_out[1] | ((int64_t)plan_out[2] << 32);
+      if (plan_out[0] < 0 || plan_out[0] > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", plan_out[0], (long long)wg_bound);
+      if (floats * 4 > scores_cap) use_scores = false;
+      else MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>(floats, 4) * 4));
+    }
   }
-  int n_wg = 0;
+  int n_wg = -1;   // -1: still on the device (read back by mrag_ivf_last_timing if asked)
   if (use_scores) {
-    n_wg = plan_out[0];
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 7);
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
     MRAG_HIP(hipEventRecord(ix->ev[1], stream));
-    MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, n_wg,
-                       (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
+    if (no_sync) {
+      MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, (int)wg_bound, d_nwg,
+                         (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
+    } else {
+      n_wg = plan_out[0];
+      MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, n_wg, nullptr,
+                         (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
+    }
     MRAG_TRY(ivfs_select_lists((const float*)ix->scores.p, (const int*)ix->desc.p, ix->ploc.p, nprobe, nq, k, ix->row_ids, ix->id_base,
                                d_sc, d_id, stream));
     MRAG_HIP(hipEventRecord(ix->ev[2], stream));
   } else {
+    MRAG_HIP(hipMemsetAsync(ix->gq.p, 0xFF, (size_t)wg_bound * 256 * 8, stream));   // (the gather below reads whole 256-slot slabs)
     hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
                        (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
@@ -668,6 +684,7 @@ int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms,
   MRAG_HIP(hipEventElapsedTime(&t, ix->ev[0], ix->ev[3]));
   if (out_scan_ms) *out_scan_ms = g;
   if (out_total_ms) *out_total_ms = t;
+  if (ix->last_n_wg < 0) MRAG_HIP(hipMemcpy(&ix->last_n_wg, (const int*)ix->plan.p + 3 * ix->nlist, 4, hipMemcpyDeviceToHost));   // (left on the device by the search)
   if (out_n_wg) *out_n_wg = ix->last_n_wg;
   if (out_scanned_rows) {
     // rows streamed by the list scan = sum over its workgroups of their list's length (descriptor words 2, 4)

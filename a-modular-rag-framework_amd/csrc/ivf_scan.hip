@@ -58,7 +58,8 @@ constexpr int S_STAGE = 2 * S_A_BYTES;          // 32 KiB
 template <int DT>
 __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restrict__ corpus, const uint16_t* __restrict__ queries,
                                                          int ld, int64_t zero_row, const int* __restrict__ desc, int n_desc,
-                                                         const int64_t* __restrict__ gq, float* __restrict__ S) {
+                                                         const int* __restrict__ n_desc_dev, const int64_t* __restrict__ gq,
+                                                         float* __restrict__ S) {
   typedef typename SMfma<DT>::frag frag;
   __shared__ __attribute__((aligned(16))) char sm[2 * S_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -66,9 +67,11 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
   const int wm = w >> 1, wn = w & 1;
   // blocks go to XCDs round-robin: give each XCD a contiguous run of descriptors (the workgroups of one list
   // are neighbours, so the list is fetched from HBM into ONE L2)
-  const int per = (int)gridDim.x >> 3;
+  const int n_real = n_desc_dev ? *n_desc_dev : n_desc;     // (n_desc_dev: the count is still on the device -- the grid is its host-side bound)
+  const int per = (n_real + 7) >> 3;
+  if ((int)(blockIdx.x >> 3) >= per) return;
   const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (lin >= n_desc) return;
+  if (lin >= n_real) return;
   const int* d = desc + (size_t)lin * IVFS_DESC_WORDS;
   const int gq_base = d[0], nq_local = d[1], n_rows = d[3], r_off = d[4], pitch = d[7];
   const int64_t row0 = (int64_t)(uint32_t)d[2];
@@ -256,15 +259,22 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
     uint32_t kr[SEL_EPT];
     uint32_t tmax = 0u;
     {
+      // all loads first (no use of a loaded value inside this loop: the <= 32 loads of a thread are in flight together)
+      float raw[SEL_EPT];
       int j = 0;
 #pragma unroll
       for (int i = 0; i < SEL_EPT; ++i) {
         const int e = tid + i * SEL_THR;
-        uint32_t key = 0u;                          // below every real key (s_f32_ord never returns 0 for a non-NaN score)
+        raw[i] = 0.f;
         if (e < total) {
           if (!DENSE) while (seg_pre[j + 1] <= e) ++j;
-          key = s_f32_ord(seg_ptr[j][e - seg_pre[j]]);
+          raw[i] = seg_ptr[j][e - seg_pre[j]];
         }
+      }
+#pragma unroll
+      for (int i = 0; i < SEL_EPT; ++i) {
+        const int e = tid + i * SEL_THR;
+        const uint32_t key = e < total ? s_f32_ord(raw[i]) : 0u;   // 0: below every real key (s_f32_ord never returns 0 for a non-NaN score)
         kr[i] = key;
         tmax = key > tmax ? key : tmax;
       }
@@ -379,12 +389,12 @@ __global__ void ivfs_dense_desc_kernel(int* __restrict__ desc, int n_qt, int n_c
 }
 
 int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype, int64_t zero_row, const int* desc, int n_desc,
-              const int64_t* gq, float* S, hipStream_t stream) {
+              const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream) {
   if (n_desc <= 0) return MRAG_OK;
   if (ld % SK) return fail(MRAG_ERR_INVALID, "ivfs_scan: ld %d is not a multiple of %d", ld, SK);
   const unsigned grid = (unsigned)((n_desc + 7) / 8 * 8);
-  if (dtype == MRAG_F16) hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_F16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, gq, S);
-  else hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_BF16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, gq, S);
+  if (dtype == MRAG_F16) hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_F16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S);
+  else hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_BF16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
@@ -417,7 +427,7 @@ int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries,
   hipLaunchKernelGGL(ivfs_dense_desc_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, desc, n_qt, n_chunks, nq, n_rows,
                      IVFS_DENSE_ROWS, pitch);
   MRAG_HIP(hipGetLastError());
-  MRAG_TRY(ivfs_scan(corpus, queries, ld, dtype, 0, desc, nd, nullptr, S, stream));
+  MRAG_TRY(ivfs_scan(corpus, queries, ld, dtype, 0, desc, nd, nullptr, nullptr, S, stream));
   SelParams p{};
   p.S = S; p.nprobe = 1; p.k = k; p.dense_rows = n_rows; p.dense_pitch = pitch; p.out_scores = out_scores; p.out_ids = out_ids;
   hipLaunchKernelGGL((ivfs_select_kernel<true>), dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
