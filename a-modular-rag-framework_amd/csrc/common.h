@@ -96,13 +96,15 @@ int64_t bf_round_rows(int64_t n);     // rows rounded up to the kernel's tile (2
 //   [0] gq base: slot s of the workgroup scores query row gq[base + s] (< 0: none); or -1 - first for the
 //       identity map (queries first .. first + 127)          [1] queries (<= 128)
 //   [2] first corpus row            [3] rows to score          [4] index of the first row inside the segment
-//   [5],[6] float offset of the workgroup's score block S[slot][pitch] (low, high)        [7] pitch (floats, % 4 == 0)
+//   [5],[6] float offset of the workgroup's score block S[slot][pitch] (low, high)        [7] pitch (floats, % 32 == 0)
 constexpr int IVFS_DESC_WORDS = 8;
 constexpr int IVFS_QUERIES = 128;       // queries per scan workgroup
+constexpr int IVFS_PITCH_ALIGN = 32;    // floats: every query's score segment starts on a 128-byte line
+static inline int64_t ivfs_pitch(int64_t rows) { return (rows + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN; }
 constexpr int IVFS_DENSE_ROWS = 512;    // corpus rows per workgroup of the dense (probe selection) case
 // (n_desc_dev != nullptr: the descriptor count lives on the device and n_desc is its host-side upper bound = the grid)
 int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype, int64_t zero_row, const int* desc, int n_desc,
-              const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream);
+              const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream, long long* dbg = nullptr);
 int ivfs_select_lists(const float* S, const int* desc, const void* ploc, int nprobe, int64_t nq, int k, const int64_t* row_ids,
                       int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream);
 int ivfs_dense_n_desc(int64_t nq, int n_rows);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __rest
     const int cnt = l < nlist ? lcount[l] : 0;
     const int lc = l < nlist ? list_count[l] : 0;
     const int nt = (cnt + IVFS_QUERIES - 1) / IVFS_QUERIES;
-    const int pitch = (lc + 3) & ~3;
+    const int pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
     const long long fl = (long long)cnt * pitch;
     part[tid] = nt;
     fpart[tid] = fl;
@@ -561,9 +561,9 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     const int64_t np_ = nq * nprobe;
     hipLaunchKernelGGL(ivf_all_lists_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, stream, (int64_t*)ix->tmp_id.p, np_, ix->nlist);
     MRAG_HIP(hipGetLastError());
-  } else if (round_up(nq, IVFS_QUERIES) * (int64_t)((ix->nlist + 3) & ~3) * 4 <= scores_cap) {
+  } else if (round_up(nq, IVFS_QUERIES) * ivfs_pitch(ix->nlist) * 4 <= scores_cap) {
     MRAG_TRY(ix->sdesc.ensure((size_t)ivfs_dense_n_desc(nq, ix->nlist) * IVFS_DESC_WORDS * 4));
-    MRAG_TRY(ix->scores.ensure((size_t)(round_up(nq, IVFS_QUERIES) * (int64_t)((ix->nlist + 3) & ~3) * 4)));
+    MRAG_TRY(ix->scores.ensure((size_t)(round_up(nq, IVFS_QUERIES) * ivfs_pitch(ix->nlist) * 4)));
     MRAG_TRY(ivfs_dense_topk(ix->cen, ix->nlist, (const uint16_t*)ix->qbuf.p, nq, ix->ld, ix->dtype, nprobe, (int*)ix->sdesc.p,
                              (float*)ix->scores.p, (float*)ix->tmp_sc.p, (int64_t*)ix->tmp_id.p, stream));
   } else {
@@ -595,7 +595,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   // Score floats of this search: known exactly only on the device (sum over the probed lists of queries x rows).  When
   // even the bound "every pair probes the longest list" fits the buffer, nothing comes back to the host at all: the
   // scan is launched over the BOUND of the workgroup count and reads the real one from device memory.
-  const int64_t max_pitch = ((int64_t)ix->max_list_rows + 3) & ~3ll;
+  const int64_t max_pitch = ivfs_pitch(ix->max_list_rows);
   const bool no_sync = use_scores && (int64_t)npairs * max_pitch * 4 <= scores_cap;
   int plan_out[3] = {0, 0, 0};
   if (use_scores) {
@@ -620,9 +620,18 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
     MRAG_HIP(hipEventRecord(ix->ev[1], stream));
+    static const char* stamp_path = getenv("MRAG_IVFS_STAMPS");   // diagnostic builds (MRAG_IVFS_DIAG & 128): per-workgroup clock stamps -> file
+    long long* dbg = nullptr;
+    if (stamp_path) { MRAG_TRY(ix->qg.ensure((size_t)wg_bound * 64)); MRAG_HIP(hipMemsetAsync(ix->qg.p, 0, (size_t)wg_bound * 64, stream)); dbg = (long long*)ix->qg.p; }
     if (no_sync) {
       MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, (int)wg_bound, d_nwg,
-                         (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
+                         (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream, dbg));
+      if (stamp_path) {
+        std::vector<long long> h((size_t)wg_bound * 8);
+        MRAG_HIP(hipStreamSynchronize(stream));
+        MRAG_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(stamp_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+      }
     } else {
       n_wg = plan_out[0];
       MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, n_wg, nullptr,

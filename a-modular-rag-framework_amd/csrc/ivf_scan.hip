@@ -24,6 +24,9 @@
 // score buffer (exhaustive probing of a big index) the caller falls back to the fused kernel.
 #include "common.h"
 
+#include <stdlib.h>
+#include <algorithm>
+
 namespace mrag {
 
 typedef _Float16 s_f16x8 __attribute__((ext_vector_type(8)));
@@ -51,27 +54,45 @@ __device__ __forceinline__ float s_ord_f32(uint32_t o) {
 }
 
 constexpr int ST = 128, SK = 64, STHR = 256;
+// timing-only ablations (make EXTRA=-DMRAG_IVFS_DIAG=<bits>; results are wrong by design):
+//   1 no score stores | 2 no MFMA | 4 queries not gathered (slot s reads row s) | 8 no corpus loads
+//   128 clock stamps of every workgroup into `dbg` (tools/ivf_stamps2.py) | 256 load and multiply the padding too
+//   16 scores stored as the register image (1 KiB per instruction) | 32 non-temporal score stores | 64 stores into a small window
+#ifdef MRAG_IVFS_DIAG
+#define IVFS_DBG(bit) ((MRAG_IVFS_DIAG) & (bit))
+#else
+#define IVFS_DBG(bit) 0
+#endif
 constexpr int S_A_BYTES = ST * SK * 2;          // 16 KiB: corpus rows of a stage
 constexpr int S_STAGE = 2 * S_A_BYTES;          // 32 KiB
 
 // descriptor words (IVFS_DESC_WORDS ints per workgroup), see common.h
+// Two LDS stages; deeper rings (3 / 4 stages behind counted vmcnt waits) were measured and change nothing: in-kernel
+// stamps show 1.85 us per K step per workgroup with two workgroups per CU = 35 GB/s per CU of L2 -> LDS traffic, the
+// same request-side bound as the fused kernel's stream.  What pays is not fetching padding: a workgroup
+// loads and multiplies only the 8-row chunks / 16-row fragments that hold real rows and real queries.
 template <int DT>
 __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restrict__ corpus, const uint16_t* __restrict__ queries,
                                                          int ld, int64_t zero_row, const int* __restrict__ desc, int n_desc,
                                                          const int* __restrict__ n_desc_dev, const int64_t* __restrict__ gq,
-                                                         float* __restrict__ S) {
+                                                         float* __restrict__ S, long long* __restrict__ dbg) {
   typedef typename SMfma<DT>::frag frag;
-  __shared__ __attribute__((aligned(16))) char sm[2 * S_STAGE];
+  constexpr int NS = 2;
+  __shared__ __attribute__((aligned(16))) char sm[NS * S_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
   // blocks go to XCDs round-robin: give each XCD a contiguous run of descriptors (the workgroups of one list
   // are neighbours, so the list is fetched from HBM into ONE L2)
-  const int n_real = n_desc_dev ? *n_desc_dev : n_desc;     // (n_desc_dev: the count is still on the device -- the grid is its host-side bound)
+  const int n_real = n_desc_dev ? *n_desc_dev : n_desc;     // (n_desc_dev: the count is still on the device)
   const int per = (n_real + 7) >> 3;
-  if ((int)(blockIdx.x >> 3) >= per) return;
-  const int lin = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (lin >= n_real) return;
+  // persistent: the grid is two workgroups per CU, each walks its XCD's run of descriptors with stride gridDim/8
+  for (int it = (int)(blockIdx.x >> 3); it < per; it += (int)(gridDim.x >> 3)) {
+  const int lin = (int)(blockIdx.x & 7) * per + it;
+  if (lin >= n_real) break;
+  __syncthreads();                                           // every wave is done with the previous descriptor's LDS stages
+#define IVFS_STAMP(i) do { if (IVFS_DBG(128) && dbg && tid == 0) dbg[(size_t)lin * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+  IVFS_STAMP(0);
   const int* d = desc + (size_t)lin * IVFS_DESC_WORDS;
   const int gq_base = d[0], nq_local = d[1], n_rows = d[3], r_off = d[4], pitch = d[7];
   const int64_t row0 = (int64_t)(uint32_t)d[2];
@@ -90,33 +111,47 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
     a_src[i] = corpus + (size_t)(row0 + r) * ld + kc * 8;
     int64_t qrow;
     if (gq_base < 0) qrow = (int64_t)(-1 - gq_base) + r;                 // identity: queries first .. first + 127 (the buffer is padded)
+    else if (IVFS_DBG(4)) qrow = r;
     else { qrow = r < nq_local ? gq[(size_t)gq_base + r] : -1; if (qrow < 0) qrow = zero_row; }
     b_src[i] = queries + (size_t)qrow * ld + kc * 8;
   }
-  auto stage = [&](int step, int buf) {
-    const int t = step / nk, kk = step - t * nk;
-    char* la = sm + buf * S_STAGE + (4 * w) * 1024;
+  const int n_steps = n_tiles * nk;
+  // issue the loads of the next K step: only the 1-KiB chunks (8 rows) that hold rows of the list / queries of the group
+  // (the rest of the LDS stage keeps whatever it held: those rows' scores are never stored)
+  int st_t = 0, st_kk = 0, st_buf = 0;                                    // cursor of the NEXT step to stage
+  auto stage_next = [&]() {
+    char* la = sm + st_buf * S_STAGE + (4 * w) * 1024;
     char* lb = la + S_A_BYTES;
-    const size_t a_adv = (size_t)t * ST * ld + (size_t)kk * SK;
+    const size_t a_adv = (size_t)st_t * ST * ld + (size_t)st_kk * SK;
+    const int rows_left = IVFS_DBG(256) ? ST : n_rows - st_t * ST, q_left = IVFS_DBG(256) ? ST : nq_local;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((s_glb_vptr)(a_src[i] + a_adv), (s_lds_vptr)(la + i * 1024), 16, 0, 0);
+      if ((4 * w + i) * 8 < rows_left && !IVFS_DBG(8))
+        __builtin_amdgcn_global_load_lds((s_glb_vptr)(a_src[i] + a_adv), (s_lds_vptr)(la + i * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((s_glb_vptr)(b_src[i] + kk * SK), (s_lds_vptr)(lb + i * 1024), 16, 0, 0);
+      if ((4 * w + i) * 8 < q_left)
+        __builtin_amdgcn_global_load_lds((s_glb_vptr)(b_src[i] + st_kk * SK), (s_lds_vptr)(lb + i * 1024), 16, 0, 0);
+    if (++st_kk == nk) { st_kk = 0; ++st_t; }
+    st_buf ^= 1;
   };
   const int frow = lane & 15, fsw = frow >> 1;
   const int a_rd = (wm * 64 + frow) * 128, b_rd = S_A_BYTES + (wn * 64 + frow) * 128;
   const int ph0 = ((lane >> 4) ^ fsw) * 16;
   s_f32x4 acc[4][4];
-  const int n_steps = n_tiles * nk;
-  float* Sb = S + soff;
-  stage(0, 0);
-  __syncthreads();
-  int kk = 0, tile = 0;
+  float* Sb = S + (IVFS_DBG(64) ? (int64_t)(lin & 63) * 32768 : soff);   // diag 64: every workgroup stores into a small L2-resident window
+  int staged = 0;
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (staged < n_steps) { stage_next(); ++staged; }
+  int kk = 0, tile = 0, buf = 0;
+  IVFS_STAMP(1);
   for (int step = 0; step < n_steps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < n_steps) stage(step + 1, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of stage `step` have landed (and its score stores of the previous tile)
+    __builtin_amdgcn_s_barrier();          // everyone's pieces of the stage are in LDS; everyone is done with the buffer restaged below
+    asm volatile("" ::: "memory");
+    if (step == 0) IVFS_STAMP(2);
+    if (staged < n_steps) { stage_next(); ++staged; }
     const char* sb = sm + buf * S_STAGE;
     if (kk == 0) {
 #pragma unroll
@@ -124,20 +159,29 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (s_f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // this wave's 64 x 64 piece: only the 16-row / 16-query fragments that hold real rows / queries (wave-uniform tests)
+    const int ni = IVFS_DBG(256) ? 4 : min(4, (n_rows - tile * ST - wm * 64 + 15) >> 4);
+    const int nj = IVFS_DBG(256) ? 4 : min(4, (nq_local - wn * 64 + 15) >> 4);
+    if (ni > 0 && nj > 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ph = ks ? (ph0 ^ 64) : ph0;
-      frag af[4], bf[4];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ph = ks ? (ph0 ^ 64) : ph0;
+        frag af[4], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const frag*)(sb + a_rd + i * 2048 + ph);
+        for (int i = 0; i < 4; ++i) if (i < ni) af[i] = *(const frag*)(sb + a_rd + i * 2048 + ph);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *(const frag*)(sb + b_rd + j * 2048 + ph);
+        for (int j = 0; j < 4; ++j) if (j < nj) bf[j] = *(const frag*)(sb + b_rd + j * 2048 + ph);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = SMfma<DT>::run(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j)
+            if (i < ni && j < nj) { if (!IVFS_DBG(2)) acc[i][j] = SMfma<DT>::run(af[i], bf[j], acc[i][j]); else acc[i][j][0] += (float)af[i][0] + (float)bf[j][0]; }
+      }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of `buf` are done before it reaches the next barrier
+    buf ^= 1;
     if (++kk == nk) {
+      if (tile == n_tiles - 1) IVFS_STAMP(3);
       // scores of this tile: lane holds rows r0..r0+3 (consecutive) of query slot q per accumulator
       const int rl = tile * ST + wm * 64 + (lane >> 4) * 4;
       const int rows4 = (n_rows + 3) & ~3;
@@ -149,13 +193,21 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r0 = rl + i * 16;
-          if (r0 < rows4) *(s_f32x4*)(sq + r0) = acc[i][j];
+          if (IVFS_DBG(16)) { if (r0 < rows4) *(s_f32x4*)(Sb + ((size_t)((tile * 4 + w) * 16 + i * 4 + j) * 64 + lane) * 4) = acc[i][j]; }   // register image: 1 KiB per instruction
+          else if (IVFS_DBG(32)) { if (r0 < rows4) __builtin_nontemporal_store(acc[i][j], (s_f32x4*)(sq + r0)); }
+          else if (r0 < rows4 && (!IVFS_DBG(1) || acc[i][j][0] == 123456.789f)) *(s_f32x4*)(sq + r0) = acc[i][j];
         }
       }
       kk = 0;
       ++tile;
+      if (IVFS_DBG(128) && tile == n_tiles) {
+        IVFS_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IVFS_STAMP(5);
+        if (dbg && tid == 0) { dbg[(size_t)lin * 8 + 6] = n_steps; dbg[(size_t)lin * 8 + 7] = (long long)nq_local << 32 | (unsigned)n_rows; }
+      }
     }
-    __syncthreads();
+  }
   }
 }
 
@@ -389,12 +441,16 @@ __global__ void ivfs_dense_desc_kernel(int* __restrict__ desc, int n_qt, int n_c
 }
 
 int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype, int64_t zero_row, const int* desc, int n_desc,
-              const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream) {
+              const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream, long long* dbg) {
   if (n_desc <= 0) return MRAG_OK;
   if (ld % SK) return fail(MRAG_ERR_INVALID, "ivfs_scan: ld %d is not a multiple of %d", ld, SK);
-  const unsigned grid = (unsigned)((n_desc + 7) / 8 * 8);
-  if (dtype == MRAG_F16) hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_F16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S);
-  else hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_BF16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S);
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t pr; int dev = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  static const int wg_per_cu = [] { const char* e = getenv("MRAG_IVFS_WG_PER_CU"); return e ? atoi(e) : 2; }();
+  const unsigned grid = wg_per_cu > 0 ? (unsigned)std::min<int64_t>((int64_t)(n_desc + 7) / 8 * 8, (int64_t)cus * wg_per_cu / 8 * 8)
+                                      : (unsigned)((n_desc + 7) / 8 * 8);      // (0: one workgroup per descriptor)
+  if (dtype == MRAG_F16) hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_F16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S, dbg);
+  else hipLaunchKernelGGL((ivfs_scan_kernel<MRAG_BF16>), dim3(grid), dim3(STHR), 0, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S, dbg);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
@@ -412,7 +468,7 @@ int ivfs_select_lists(const float* S, const int* desc, const void* ploc, int npr
 }
 
 // top-k rows of a dense [nq] x [n_rows] problem (probe selection): descriptors, scan, select.  `desc` must hold
-// ivfs_dense_n_desc(nq, n_rows) descriptors, S nq_round128 x pitch floats with pitch = round4(n_rows).
+// ivfs_dense_n_desc(nq, n_rows) descriptors, S nq_round128 x ivfs_pitch(n_rows) floats.
 int ivfs_dense_n_desc(int64_t nq, int n_rows) {
   return (int)((nq + ST - 1) / ST) * ((n_rows + IVFS_DENSE_ROWS - 1) / IVFS_DENSE_ROWS);
 }
@@ -422,7 +478,7 @@ int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries,
   if (nq <= 0) return MRAG_OK;
   if (k > SEL_MAXK) return fail(MRAG_ERR_UNSUPPORTED, "ivfs_dense_topk: k %d above %d", k, SEL_MAXK);
   const int n_qt = (int)((nq + ST - 1) / ST), n_chunks = (n_rows + IVFS_DENSE_ROWS - 1) / IVFS_DENSE_ROWS;
-  const int pitch = (n_rows + 3) & ~3;
+  const int pitch = (int)ivfs_pitch(n_rows);
   const int nd = n_qt * n_chunks;
   hipLaunchKernelGGL(ivfs_dense_desc_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, desc, n_qt, n_chunks, nq, n_rows,
                      IVFS_DENSE_ROWS, pitch);
