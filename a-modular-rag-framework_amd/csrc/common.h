@@ -105,7 +105,8 @@ constexpr int IVFS_DENSE_ROWS = 512;    // corpus rows per workgroup of the dens
 // (n_desc_dev != nullptr: the descriptor count lives on the device and n_desc is its host-side upper bound = the grid)
 int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype, int64_t zero_row, const int* desc, int n_desc,
               const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream, long long* dbg = nullptr);
-int ivfs_select_lists(const float* S, const int* desc, const void* ploc, int nprobe, int64_t nq, int k, const int64_t* row_ids,
+// pinfo: int4 per (query, probe) = (float offset of the pair's score segment: low, high; its rows; its first stored row)
+int ivfs_select_lists(const float* S, const void* pinfo, int nprobe, int64_t nq, int k, const int64_t* row_ids,
                       int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream);
 int ivfs_dense_n_desc(int64_t nq, int n_rows);
 int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries, int64_t nq, int ld, int dtype, int k, int* desc,

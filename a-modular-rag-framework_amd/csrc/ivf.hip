@@ -126,15 +126,26 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ 
 
 __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
                                    const int* __restrict__ list_count, const int* __restrict__ wg_first,
-                                   int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc, int qshift) {
+                                   int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc, int qshift,
+                                   const int* __restrict__ sdesc, int4* __restrict__ pinfo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npairs) return;
   const int64_t l = probes[i];
-  if (l < 0 || list_count[l] == 0) { ploc[i] = make_int2(-1, 0); return; }
+  if (l < 0 || list_count[l] == 0) {
+    if (pinfo) pinfo[i] = make_int4(0, 0, 0, 0); else ploc[i] = make_int2(-1, 0);
+    return;
+  }
   const int pos = atomicAdd(&cursor[l], 1);
   const int wgi = wg_first[l] + (pos >> qshift), slot = pos & ((1 << qshift) - 1);   // 2^qshift queries per workgroup
   gq[((size_t)wgi << qshift) + slot] = i / nprobe;
-  ploc[i] = make_int2(wgi, slot);
+  if (pinfo) {
+    // score-segment regime: everything the per-query selection needs about this pair, in one 16-byte record
+    const int* d = sdesc + (size_t)wgi * IVFS_DESC_WORDS;
+    const long long so = ((long long)(unsigned)d[5] | ((long long)d[6] << 32)) + (long long)slot * d[7];
+    pinfo[i] = make_int4((int)(unsigned)(so & 0xFFFFFFFFll), (int)(so >> 32), d[3], d[2]);
+  } else {
+    ploc[i] = make_int2(wgi, slot);
+  }
 }
 
 // Plan of the "score segments + select" regime (ivf_scan.hip): workgroups of <= 128 queries, each list's scores
@@ -586,7 +597,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   int* d_nwg = d_cursor + nl;
   MRAG_TRY(ix->desc.ensure((size_t)wg_bound * 8 * 4));
   MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
-  MRAG_TRY(ix->ploc.ensure(npairs * 8));
+  MRAG_TRY(ix->ploc.ensure(npairs * 16));   // int2 (fused regime) or int4 (score segments) per pair
   MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
   hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
@@ -616,7 +627,8 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   int n_wg = -1;   // -1: still on the device (read back by mrag_ivf_last_timing if asked)
   if (use_scores) {
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
-                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 7);
+                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, nullptr, 7,
+                       (const int*)ix->desc.p, (int4*)ix->ploc.p);
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
     MRAG_HIP(hipEventRecord(ix->ev[1], stream));
@@ -637,15 +649,15 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
       MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, n_wg, nullptr,
                          (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
     }
-    MRAG_TRY(ivfs_select_lists((const float*)ix->scores.p, (const int*)ix->desc.p, ix->ploc.p, nprobe, nq, k, ix->row_ids, ix->id_base,
-                               d_sc, d_id, stream));
+    MRAG_TRY(ivfs_select_lists((const float*)ix->scores.p, ix->ploc.p, nprobe, nq, k, ix->row_ids, ix->id_base, d_sc, d_id, stream));
     MRAG_HIP(hipEventRecord(ix->ev[2], stream));
   } else {
     MRAG_HIP(hipMemsetAsync(ix->gq.p, 0xFF, (size_t)wg_bound * 256 * 8, stream));   // (the gather below reads whole 256-slot slabs)
     hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
                        (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
-                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8);
+                       (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8,
+                       nullptr, nullptr);
     MRAG_HIP(hipGetLastError());
     MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipStreamSynchronize(stream));

@@ -221,8 +221,7 @@ constexpr int SEL_MAXK = 256;
 
 struct SelParams {
   const float* S;
-  const int* desc;            // lists: descriptors of the scan; dense: unused
-  const int2* ploc;           // lists: (descriptor, query slot) per (query, probe); dense: unused
+  const int4* pinfo;          // lists: per (query, probe) the score segment (float offset low / high, rows, first stored row); dense: unused
   const int64_t* row_ids;     // lists: stored position -> original row; dense: nullptr (row = position)
   int nprobe, k;
   int dense_rows;             // dense: rows per segment
@@ -278,23 +277,30 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
       ptr = p.S + (size_t)q * p.dense_pitch;
       cnt = p.dense_rows;
     } else {
-      const int2 loc = p.ploc[(size_t)q * np + tid];
-      if (loc.x >= 0) {
-        const int* d = p.desc + (size_t)loc.x * IVFS_DESC_WORDS;
-        const int64_t soff = (int64_t)(uint32_t)d[5] | ((int64_t)d[6] << 32);
-        ptr = p.S + soff + (size_t)loc.y * d[7];
-        cnt = d[3];
-        r0 = (int64_t)(uint32_t)d[2];
+      const int4 pi = p.pinfo[(size_t)q * np + tid];     // (segment offset low, high, rows, first stored row); rows = 0: none
+      if (pi.z > 0) {
+        ptr = p.S + ((int64_t)(uint32_t)pi.x | ((int64_t)pi.y << 32));
+        cnt = pi.z;
+        r0 = (int64_t)(uint32_t)pi.w;
       }
     }
     seg_ptr[tid] = ptr; seg_cnt[tid] = cnt; seg_row0[tid] = r0;
   }
   if (tid == 0) n_cand = 0;
   __syncthreads();
-  if (tid == 0) {
-    int s = 0;
-    for (int j = 0; j < np; ++j) { seg_pre[j] = s; s += seg_cnt[j]; }
-    seg_pre[np] = s;
+  if (w == 0) {                                      // prefix sums of the <= 256 segment lengths: 4 per lane + a wave scan
+    int c[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int j = lane * 4 + i; c[i] = j < np ? seg_cnt[j] : 0; sum += c[i]; }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int j = lane * 4 + i; if (j < np) seg_pre[j] = run; run += c[i]; }
+    if (lane == 63) seg_pre[np] = incl;
   }
   __syncthreads();
   const int total = seg_pre[np];
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
       }
     }
     // k-th largest of the 256 thread maxima: the largest P with #(tmax >= P) >= k, two bits per step
+    // (four bits per step -- 15 ballots, half the barriers -- was slower: the 64-bit unpacking of 15 counts outweighs them)
     uint32_t P = 0u;
     for (int bit = 30; bit >= 0; bit -= 2) {
       const uint32_t c1 = P | (1u << bit), c2 = P | (2u << bit), c3 = P | (3u << bit);
@@ -345,12 +352,19 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
       P = N3 >= k ? c3 : N2 >= k ? c2 : N1 >= k ? c1 : P;
     }
     // shortlist
+    // (wave-aggregated append: one LDS atomic per wave and register slot that has any hit -- a lane-by-lane atomicAdd on the
+    // one counter serialises ~k lanes)
 #pragma unroll
     for (int i = 0; i < SEL_EPT; ++i) {
       const int e = tid + i * SEL_THR;
-      if (e < total && kr[i] >= P) {
-        const int c = atomicAdd(&n_cand, 1);
-        if (c < SEL_CAND) { cand_key[c] = kr[i]; cand_e[c] = (uint32_t)e; }
+      const bool hit = e < total && kr[i] >= P;
+      const unsigned long long hm = __ballot(hit);
+      if (hm) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&n_cand, (int)__popcll(hm));
+        base = __shfl(base, 0);
+        const int c = base + (int)__popcll(hm & ((1ull << lane) - 1ull));
+        if (hit && c < SEL_CAND) { cand_key[c] = kr[i]; cand_e[c] = (uint32_t)e; }
       }
     }
     __syncthreads();
@@ -455,12 +469,12 @@ int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype
   return MRAG_OK;
 }
 
-int ivfs_select_lists(const float* S, const int* desc, const void* ploc, int nprobe, int64_t nq, int k, const int64_t* row_ids,
+int ivfs_select_lists(const float* S, const void* pinfo, int nprobe, int64_t nq, int k, const int64_t* row_ids,
                       int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream) {
   if (nq <= 0) return MRAG_OK;
   if (nprobe > SEL_MAXP || k > SEL_MAXK) return fail(MRAG_ERR_UNSUPPORTED, "ivfs_select: nprobe %d / k %d above %d / %d", nprobe, k, SEL_MAXP, SEL_MAXK);
   SelParams p{};
-  p.S = S; p.desc = desc; p.ploc = (const int2*)ploc; p.row_ids = row_ids; p.nprobe = nprobe; p.k = k;
+  p.S = S; p.pinfo = (const int4*)pinfo; p.row_ids = row_ids; p.nprobe = nprobe; p.k = k;
   p.id_base = id_base; p.out_scores = out_scores; p.out_ids = out_ids;
   hipLaunchKernelGGL((ivfs_select_kernel<false>), dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
   MRAG_HIP(hipGetLastError());
