@@ -162,3 +162,38 @@ def test_fused_regime_gives_the_same_answer():
         for key in res["scores"].files:
             a, b = res["scores"][key], res["fused"][key]
             assert np.array_equal(a, b), key
+
+
+def test_bf16_storage_and_exact_integer_ties():
+    """bf16 storage through the score-segment scan, and small-integer rows (inner product): every partial sum is exact
+    in fp32, so scores and ids must equal the oracle's exactly -- ties, which are many, included."""
+    import torch
+    from mrag_amd.index import IVFFlatIndex
+    n, nq, d, nlist, nprobe, k = 12000, 100, 128, 32, 8, 10
+    rows, qs = ds.make_clustered(n, nq, d, 41, n_centroids=32)
+    c = torch.from_numpy(ds.l2_normalize(rows)).to(torch.bfloat16)
+    q = torch.from_numpy(ds.l2_normalize(qs)).to(torch.bfloat16)
+    cen = torch.from_numpy(ds.kmeans_spherical(c.float().numpy(), nlist, 3, seed=1, dtype=np.float32)).to(torch.bfloat16)
+    ix = IVFFlatIndex(d, nlist, dtype="bf16")
+    ix.set_centroids(cen, normalize=False)
+    ix.add(c, normalize=False)
+    sc, ids = ix.search(q, k, nprobe, normalize=False)
+    rv, ri = ds.ivf_search(q.double().numpy(), c.double().numpy(), cen.double().numpy(), ix.assignments().astype(np.int64), nprobe, k)
+    np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+    strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
+    assert bad <= 0.002 * nq * k
+
+    rng = np.random.default_rng(9)
+    ci = rng.integers(-2, 3, size=(6000, 64)).astype(np.float16)
+    qi = rng.integers(-2, 3, size=(64, 64)).astype(np.float16)
+    ceni = rng.integers(-2, 3, size=(16, 64)).astype(np.float16)
+    ixi = IVFFlatIndex(64, 16, metric="ip")
+    ixi.set_centroids(ceni, normalize=False)
+    ixi.add(ci, normalize=False)
+    a = ixi.assignments().astype(np.int64)
+    assert np.array_equal(a, ds.ivf_assign(ci, ceni))
+    for kk, npb in ((10, 4), (64, 8), (1, 1)):
+        sc, ids = ixi.search(qi, kk, npb, normalize=False)
+        rv, ri = ds.ivf_search(qi, ci, ceni, a, npb, kk)
+        assert np.array_equal(ids, ri), (kk, npb)
+        assert np.array_equal(sc, rv.astype(np.float32))
