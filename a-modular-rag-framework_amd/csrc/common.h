@@ -101,7 +101,7 @@ constexpr int IVFS_DESC_WORDS = 8;
 constexpr int IVFS_QUERIES = 128;       // queries per scan workgroup
 constexpr int IVFS_PITCH_ALIGN = 32;    // floats: every query's score segment starts on a 128-byte line
 static inline int64_t ivfs_pitch(int64_t rows) { return (rows + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN; }
-constexpr int IVFS_DENSE_ROWS = 512;    // corpus rows per workgroup of the dense (probe selection) case
+constexpr int IVFS_DENSE_ROWS = 128;    // corpus rows per descriptor of the dense (probe selection) case: one tile, so that the persistent grid balances
 // (n_desc_dev != nullptr: the descriptor count lives on the device and n_desc is its host-side upper bound = the grid)
 int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype, int64_t zero_row, const int* desc, int n_desc,
               const int* n_desc_dev, const int64_t* gq, float* S, hipStream_t stream, long long* dbg = nullptr);
@@ -109,7 +109,10 @@ int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype
 int ivfs_select_lists(const float* S, const void* pinfo, int nprobe, int64_t nq, int k, const int64_t* row_ids,
                       int64_t id_base, float* out_scores, int64_t* out_ids, hipStream_t stream);
 int ivfs_dense_n_desc(int64_t nq, int n_rows);
+// count_out != nullptr: every selected row r with row_weight[r] > 0 also bumps count_out[r] (the IVF search's
+// "queries per list" histogram, otherwise a kernel of its own)
 int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries, int64_t nq, int ld, int dtype, int k, int* desc,
-                    float* S, float* out_scores, int64_t* out_ids, hipStream_t stream);
+                    float* S, float* out_scores, int64_t* out_ids, hipStream_t stream, int* count_out = nullptr,
+                    const int* row_weight = nullptr);
 
 }  // namespace mrag

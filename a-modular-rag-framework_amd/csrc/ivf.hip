@@ -568,6 +568,14 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   // fp32 segments of this search fit the score buffer; otherwise (exhaustive probing of a big index) as the fused
   // GEMM + top-k kernel in descriptor mode.  MRAG_IVF_SCORES_MB = 0 forces the fused path (tests).
   static const int64_t scores_cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 4096) << 20; }();
+  const int nl = ix->nlist;
+  MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
+  int* d_lcount = (int*)ix->plan.p;      // queries per list | first workgroup of the list | cursor | workgroup count, score floats
+  int* d_wg_first = d_lcount + nl;
+  int* d_cursor = d_wg_first + nl;
+  int* d_nwg = d_cursor + nl;
+  MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
+  bool counted = false;                  // the probe selection below can fill d_lcount itself
   if (nprobe == ix->nlist) {
     const int64_t np_ = nq * nprobe;
     hipLaunchKernelGGL(ivf_all_lists_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, stream, (int64_t*)ix->tmp_id.p, np_, ix->nlist);
@@ -576,7 +584,9 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     MRAG_TRY(ix->sdesc.ensure((size_t)ivfs_dense_n_desc(nq, ix->nlist) * IVFS_DESC_WORDS * 4));
     MRAG_TRY(ix->scores.ensure((size_t)(round_up(nq, IVFS_QUERIES) * ivfs_pitch(ix->nlist) * 4)));
     MRAG_TRY(ivfs_dense_topk(ix->cen, ix->nlist, (const uint16_t*)ix->qbuf.p, nq, ix->ld, ix->dtype, nprobe, (int*)ix->sdesc.p,
-                             (float*)ix->scores.p, (float*)ix->tmp_sc.p, (int64_t*)ix->tmp_id.p, stream));
+                             (float*)ix->scores.p, (float*)ix->tmp_sc.p, (int64_t*)ix->tmp_id.p, stream, d_lcount,
+                             (const int*)ix->d_list_count.p));
+    counted = true;
   } else {
     BfLaunch a;
     a.corpus = ix->cen; a.queries = (const uint16_t*)ix->qbuf.p; a.ld = ix->ld; a.dtype = ix->dtype; a.k = nprobe;
@@ -588,20 +598,14 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   // 2) device: list -> the queries that probe it, cut into workgroups of <= 128 (score segments) or <= 256 (fused
   //    kernel) queries.  Only the workgroup count and the size of the segments come back to the host (12 bytes).
   const size_t npairs = (size_t)nq * nprobe;
-  const int nl = ix->nlist;
   const int64_t wg_bound = (int64_t)std::min<size_t>((size_t)nl, npairs) + (int64_t)(npairs / IVFS_QUERIES) + 1;   // (covers the 256-query plan too)
-  MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
-  int* d_lcount = (int*)ix->plan.p;
-  int* d_wg_first = d_lcount + nl;
-  int* d_cursor = d_wg_first + nl;
-  int* d_nwg = d_cursor + nl;
   MRAG_TRY(ix->desc.ensure((size_t)wg_bound * 8 * 4));
   MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
   MRAG_TRY(ix->ploc.ensure(npairs * 16));   // int2 (fused regime) or int4 (score segments) per pair
-  MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
-  hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
-                     (const int*)ix->d_list_count.p, d_lcount);
+  if (!counted)
+    hipLaunchKernelGGL(ivf_count_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs,
+                       (const int*)ix->d_list_count.p, d_lcount);
   bool use_scores = scores_cap > 0 && nprobe <= 256;   // (the select kernel holds <= 256 segments per query; exhaustive probing takes the fused path)
   // Score floats of this search: known exactly only on the device (sum over the probed lists of queries x rows).  When
   // even the bound "every pair probes the longest list" fits the buffer, nothing comes back to the host at all: the

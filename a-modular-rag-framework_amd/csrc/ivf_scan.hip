@@ -229,6 +229,8 @@ struct SelParams {
   int64_t id_base;
   float* out_scores;          // [nq][k] or nullptr
   int64_t* out_ids;           // [nq][k]
+  int* count_out;             // dense, optional: histogram of the selected rows ...
+  const int* row_weight;      // ... counting only rows with row_weight > 0
 };
 
 // Selection = (score desc, original row asc), exact.
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
   auto emit = [&](int rank, uint32_t key, int64_t row) {
     if (p.out_scores) p.out_scores[q * k + rank] = s_ord_f32(key);
     p.out_ids[q * k + rank] = row + p.id_base;
+    if (DENSE && p.count_out && p.row_weight[row] > 0) atomicAdd(&p.count_out[row], 1);
   };
   const int kk = total < k ? total : k;
   bool serial = total > SEL_CAP || total <= k;     // (fewer candidates than k: all of them, in order -- the serial path does that)
@@ -488,7 +491,7 @@ int ivfs_dense_n_desc(int64_t nq, int n_rows) {
 }
 
 int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries, int64_t nq, int ld, int dtype, int k, int* desc,
-                    float* S, float* out_scores, int64_t* out_ids, hipStream_t stream) {
+                    float* S, float* out_scores, int64_t* out_ids, hipStream_t stream, int* count_out, const int* row_weight) {
   if (nq <= 0) return MRAG_OK;
   if (k > SEL_MAXK) return fail(MRAG_ERR_UNSUPPORTED, "ivfs_dense_topk: k %d above %d", k, SEL_MAXK);
   const int n_qt = (int)((nq + ST - 1) / ST), n_chunks = (n_rows + IVFS_DENSE_ROWS - 1) / IVFS_DENSE_ROWS;
@@ -500,6 +503,7 @@ int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries,
   MRAG_TRY(ivfs_scan(corpus, queries, ld, dtype, 0, desc, nd, nullptr, nullptr, S, stream));
   SelParams p{};
   p.S = S; p.nprobe = 1; p.k = k; p.dense_rows = n_rows; p.dense_pitch = pitch; p.out_scores = out_scores; p.out_ids = out_ids;
+  p.count_out = count_out; p.row_weight = row_weight;
   hipLaunchKernelGGL((ivfs_select_kernel<true>), dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
