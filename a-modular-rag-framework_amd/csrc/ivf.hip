@@ -546,6 +546,22 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   MRAG_TRY(use_device(ix->device));
   hipStream_t stream = (hipStream_t)stream_;
   MRAG_TRY(ivf_finalize(ix, stream));
+  // Large batches are cut so that a chunk's score segments fit the score buffer even if every pair probes the longest
+  // list (ivf_scan.hip's regime, without a host round trip); results are per query, so the chunks are independent.
+  {
+    static const int64_t cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 4096) << 20; }();
+    const int64_t per_query = std::max<int64_t>((int64_t)std::min(nprobe, 256) * ivfs_pitch(ix->max_list_rows), ivfs_pitch(ix->nlist)) * 4;
+    const int64_t chunk = std::max<int64_t>(1024, cap / std::max<int64_t>(per_query, 1) / IVFS_QUERIES * IVFS_QUERIES);
+    if (cap > 0 && nprobe <= 256 && nq > chunk) {
+      const size_t qrow = (size_t)ix->dim * esize(q_dtype);
+      for (int64_t off = 0; off < nq; off += chunk) {
+        const int64_t m = std::min(chunk, nq - off);
+        MRAG_TRY(mrag_ivf_search(h, (const char*)queries + (size_t)off * qrow, m, q_dtype, normalize, queries_is_device, nprobe, k,
+                                 out_scores + (size_t)off * k, out_ids + (size_t)off * k, out_is_device, stream_));
+      }
+      return MRAG_OK;   // (mrag_ivf_last_timing then reports the last chunk)
+    }
+  }
   ix->timed = false;
   MRAG_HIP(hipEventRecord(ix->ev[0], stream));
 
@@ -694,7 +710,9 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
   }
-  MRAG_HIP(hipStreamSynchronize(stream));   // host vectors above must outlive the async copies
+  // host buffers (pageable query / result memory) must not be touched by the caller before the copies are done; with
+  // queries and results in device memory the search is fully asynchronous on `stream`
+  if (!out_is_device || !queries_is_device) MRAG_HIP(hipStreamSynchronize(stream));
   return MRAG_OK;
 }
 

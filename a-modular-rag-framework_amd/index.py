@@ -308,8 +308,9 @@ class IVFFlatIndex:
         return {"scan_ms": g.value, "total_ms": t.value, "scanned_rows": rows.value, "n_wg": nwg.value}
 
     def search(self, queries, k: int, nprobe: int, normalize: Optional[bool] = None):
-        """-> (scores [nq,k], ids [nq,k]); host queries give numpy arrays, CUDA tensors give CUDA tensors
-        (the call returns when they are complete).  ``nprobe``: 1..256, or ``nlist`` (exhaustive)."""
+        """-> (scores [nq,k], ids [nq,k]); host queries give numpy arrays (complete on return), CUDA tensors give CUDA
+        tensors filled asynchronously on the current torch stream, like any torch op.  ``nprobe``: 1..256, or ``nlist``
+        (exhaustive)."""
         keep, ptr, nq, dt, is_dev = _as_buffer(queries, self.dim)
         if is_dev:
             import torch

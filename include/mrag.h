@@ -144,10 +144,15 @@ int mrag_ivf_size(mrag_handle h, int64_t* out_rows);
 int mrag_ivf_set_id_base(mrag_handle h, int64_t id_base);
 /* list id of every stored row, in insertion order */
 int mrag_ivf_get_assignments(mrag_handle h, int32_t* out, int out_is_device, void* stream);
+/* top-k over the `nprobe` nearest lists of every query (nprobe 1..256, or nlist = exhaustive); k <= 64.
+ * Order and tie-break as mrag_index_search: (score desc, original row asc); missing entries (-inf, -1).
+ * With queries AND results in device memory the call is asynchronous on `stream`; with host buffers it
+ * returns when they are complete.  Batches are cut internally so that a chunk's fp32 score segments fit the
+ * score buffer (MRAG_IVF_SCORES_MB, default 4096; 0 = always the fused GEMM + top-k kernel). */
 int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize,
                     int queries_is_device, int nprobe, int k, float* out_scores, int64_t* out_ids,
                     int out_is_device, void* stream);
-/* measurement hooks for bench.py (like mrag_index_last_timing): device ms of the list-scan kernel and of the
+/* measurement hooks for bench.py (like mrag_index_last_timing): device ms of the list scan (scan + per-query selection kernels, or the fused kernel) and of the
  * whole LAST mrag_ivf_search (hipEvents on its stream), the rows that scan streamed (sum over its
  * workgroups of their list's length: x ld x 2 = the algorithmic HBM bytes) and its workgroup count. */
 int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms, int64_t* out_scanned_rows, int* out_n_wg);

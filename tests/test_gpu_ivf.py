@@ -136,14 +136,14 @@ def test_select_ties_and_large_candidate_sets():
 
 def test_fused_regime_gives_the_same_answer():
     """MRAG_IVF_SCORES_MB=0 forces the fused GEMM + top-k kernel in descriptor mode (the regime kept for searches whose
-    score segments would not fit): same scores bit for bit, same ids."""
+    score segments would not fit), a small buffer forces query chunking: same scores bit for bit, same ids."""
     import os, subprocess, sys, tempfile, textwrap
     code = textwrap.dedent('''
         import sys, numpy as np
         sys.path.insert(0, ".")
         from oracle import dense_search as ds
         from mrag_amd.index import IVFFlatIndex
-        rows, qs = ds.make_clustered(30000, 500, 128, 31, n_centroids=64)
+        rows, qs = ds.make_clustered(30000, 3000, 128, 31, n_centroids=64)
         c16, q16 = ds.normalize_round(rows), ds.normalize_round(qs)
         cen = ds.kmeans_spherical(c16, 96, 3, seed=4)
         ix = IVFFlatIndex(128, 96); ix.set_centroids(cen, normalize=False); ix.add(c16, normalize=False)
@@ -155,13 +155,14 @@ def test_fused_regime_gives_the_same_answer():
     ''')
     with tempfile.TemporaryDirectory() as td:
         res = {}
-        for mode, env in (("scores", {}), ("fused", {"MRAG_IVF_SCORES_MB": "0"})):
+        # "chunked": a 48 MB score buffer cuts the 3 000 queries into three chunks (and sends the exhaustive case to the fused kernel)
+        for mode, env in (("scores", {}), ("fused", {"MRAG_IVF_SCORES_MB": "0"}), ("chunked", {"MRAG_IVF_SCORES_MB": "48"})):
             path = os.path.join(td, mode + ".npz")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, cwd=os.path.dirname(os.path.dirname(__file__)))
             res[mode] = np.load(path)
         for key in res["scores"].files:
-            a, b = res["scores"][key], res["fused"][key]
-            assert np.array_equal(a, b), key
+            for other in ("fused", "chunked"):
+                assert np.array_equal(res["scores"][key], res[other][key]), (key, other)
 
 
 def test_bf16_storage_and_exact_integer_ties():

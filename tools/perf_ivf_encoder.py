@@ -28,7 +28,8 @@ def ivf(n=625_000, d=768, nlist=4096, nprobe=32, nq=10_000, k=10):
     ix.search(q, k, nprobe)
     ts = []
     for _ in range(3):
-        t0 = time.perf_counter(); sc, ids = ix.search(q, k, nprobe); ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); sc, ids = ix.search(q, k, nprobe); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)   # (device in / out: the call itself is asynchronous)
     bs, bi = bf.search(q, k); torch.cuda.synchronize()
     bi = bi.cpu().numpy()
     ids = ids.cpu().numpy() if torch.is_tensor(ids) else ids
