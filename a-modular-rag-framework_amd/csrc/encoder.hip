@@ -666,6 +666,164 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const uint16_t* 
   }
 }
 
+// ------------------------------------------------------------------ attention, sequences of <= 128 tokens
+// One workgroup (4 waves) per (batch, head): K and V of the head are staged ONCE, row-major, with all global loads in flight
+// together; every wave then owns 32 query rows (two 16-row MFMA groups) against all 128 (padded) keys -- no key-block loop, no
+// online-softmax rescaling, no per-block barriers.  The two operands whose contraction index runs along LDS ROWS come from
+// gfx950's transposing LDS read (ds_read_b64_tr_b16, cdna_hip_programming.md T10):
+//   V  [key][dh]  -> B operand of P V   (lane n = dh column, 8 consecutive keys): two reads of a 4-key x 16-column block
+//   P^T[key][row] -> A operand of P V   (lane m = query row, 8 consecutive keys): the accumulator layout of Q K^T already holds
+//                    4 consecutive rows of one key per lane, so P goes to LDS as ONE 8-byte store per accumulator (the
+//                    generic kernel above writes sixteen 2-byte stores per lane and block, and eight per V chunk).
+// Row reductions of the softmax stay inside a 16-lane DPP row (row_ror), no LDS permutes.
+typedef short tr_s4 __attribute__((ext_vector_type(4)));
+template <typename F>
+__device__ __forceinline__ F tr_read_pair(const void* lo_ptr, const void* hi_ptr) {
+  typedef __attribute__((address_space(3))) tr_s4* lp;
+  union { tr_s4 h[2]; F f; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)lo_ptr);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)hi_ptr);
+  return u.f;
+}
+template <int N>
+__device__ __forceinline__ float dpp_ror16(float x) {   // value of the lane N places further round its 16-lane row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float x) {
+  x = fmaxf(x, dpp_ror16<8>(x)); x = fmaxf(x, dpp_ror16<4>(x)); x = fmaxf(x, dpp_ror16<2>(x)); return fmaxf(x, dpp_ror16<1>(x));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_ror16<8>(x); x += dpp_ror16<4>(x); x += dpp_ror16<2>(x); return x + dpp_ror16<1>(x);
+}
+
+template <int DT, int DH>
+__global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                                 uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
+  typedef typename EMfma<DT>::frag frag;
+  typedef typename EMfma<DT>::elem elem;
+  typedef elem e4 __attribute__((ext_vector_type(4)));
+  constexpr int SP = 128;                      // keys, padded
+  constexpr int NK = DH / 32;                  // k steps of Q K^T
+  constexpr int ND = DH / 16;                  // 16-column groups of the output
+  constexpr int KP = DH + 8;                   // row pitch of the K / V images (elements): 16-byte pad
+  constexpr int PIECES = DH / 8;               // 16-byte pieces per row
+  __shared__ __attribute__((aligned(16))) elem sK[SP][KP];
+  __shared__ __attribute__((aligned(16))) elem sV[SP][KP];
+  __shared__ __attribute__((aligned(16))) elem sPt[4][SP][16];     // per wave: P^T [key][query row]; afterwards its [16][DH] output slab
+  __shared__ float sBias[SP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hh = blockIdx.x % heads, bb = blockIdx.x / heads;
+  const size_t ld = (size_t)3 * H;
+  const uint16_t* base = qkv + (size_t)bb * S * ld;
+  {
+    frag kv[SP * PIECES / 256], vv[SP * PIECES / 256];
+#pragma unroll
+    for (int i = 0; i < SP * PIECES / 256; ++i) {
+      const int e = tid + i * 256, key = e / PIECES, c = e % PIECES;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kv[i][j] = (elem)0.f; vv[i][j] = (elem)0.f; }
+      if (key < S) {
+        kv[i] = *(const frag*)(base + (size_t)key * ld + H + hh * DH + c * 8);
+        vv[i] = *(const frag*)(base + (size_t)key * ld + 2 * H + hh * DH + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SP * PIECES / 256; ++i) {
+      const int e = tid + i * 256, key = e / PIECES, c = e % PIECES;
+      *(frag*)&sK[key][c * 8] = kv[i];
+      *(frag*)&sV[key][c * 8] = vv[i];
+    }
+  }
+  if (tid < SP) sBias[tid] = (tid < S && mask[(size_t)bb * S + tid] != 0) ? 0.f : -1e30f;
+  __syncthreads();
+  const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;   // tr read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+  // V fragments, shared by the wave's two row groups: vf[ks][d] = V[keys 32 ks + 8 g .. +7][dh 16 d + i16]
+  frag vf[4][ND];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+      vf[ks][d] = tr_read_pair<frag>(&sV[ks * 32 + 8 * g + tq][d * 16 + 4 * tp], &sV[ks * 32 + 8 * g + 4 + tq][d * 16 + 4 * tp]);
+  float bias[8];
+#pragma unroll
+  for (int nf = 0; nf < 8; ++nf) bias[nf] = sBias[nf * 16 + i16];
+#pragma unroll 1
+  for (int rg = 0; rg < 2; ++rg) {
+    const int row0 = w * 32 + rg * 16;
+    if (row0 >= S) break;                                                  // (wave-uniform)
+    const int q_row = row0 + i16;
+    frag qf[NK];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      frag z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (elem)0.f;
+      if (q_row < S) z = *(const frag*)(base + (size_t)q_row * ld + hh * DH + ks * 32 + g * 8);
+      qf[ks] = z;
+    }
+    // scores: lane holds rows 4 g + r, key 16 nf + i16
+    f32x4 sc[8];
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) {
+      sc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const frag kf = *(const frag*)&sK[nf * 16 + i16][ks * 32 + g * 8];
+        sc[nf] = EMfma<DT>::run(qf[ks], kf, sc[nf]);
+      }
+    }
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf) { sc[nf][r] = sc[nf][r] * scale + bias[nf]; mx = fmaxf(mx, sc[nf][r]); }
+      mx = row16_max(mx);
+      float rs = 0.f;
+#pragma unroll
+      for (int nf = 0; nf < 8; ++nf) { const float e = __expf(sc[nf][r] - mx); sc[nf][r] = e; rs += e; }
+      inv[r] = 1.0f / row16_sum(rs);
+    }
+    // P^T -> LDS: one 8-byte store per accumulator (4 consecutive query rows of one key)
+#pragma unroll
+    for (int nf = 0; nf < 8; ++nf) {
+      e4 pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk[r] = (elem)sc[nf][r];
+      *(e4*)&sPt[w][nf * 16 + i16][4 * g] = pk;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    __builtin_amdgcn_wave_barrier();
+    f32x4 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const frag pf = tr_read_pair<frag>(&sPt[w][ks * 32 + 8 * g + tq][4 * tp], &sPt[w][ks * 32 + 8 * g + 4 + tq][4 * tp]);
+#pragma unroll
+      for (int d = 0; d < ND; ++d) o[d] = EMfma<DT>::run(pf, vf[ks][d], o[d]);
+    }
+    // out[row][hh*DH + 16 d + i16], row = row0 + 4 g + r: through the wave's (now idle) P^T area as a [16][DH] slab, so that it
+    // leaves as 16-byte pieces of whole rows
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    elem* slab = &sPt[w][0][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < ND; ++d) slab[(4 * g + r) * KP + d * 16 + i16] = (elem)(o[d][r] * inv[r]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 16 * PIECES; e += 64) {
+      const int rr = e / PIECES, pc = e % PIECES;
+      const int row = row0 + rr;
+      if (row < S) *(frag*)&out[((size_t)bb * S + row) * H + hh * DH + pc * 8] = *(const frag*)&slab[rr * KP + pc * 8];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ pooling + L2 norm
 template <typename E>
 __global__ __launch_bounds__(256) void enc_pool_kernel(const E* __restrict__ x, const int32_t* __restrict__ mask, int B, int S, int H,
@@ -851,6 +1009,12 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
     MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, M_pad, EPI_BIAS, stream));
     const int32_t* am = (const int32_t*)e->mask.p;
     if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
+    static const bool s128_off = [] { const char* e = getenv("MRAG_ENC_ATTN_GENERIC"); return e && atoi(e) != 0; }();   // development switch: A/B against the generic kernel
+    if (S <= 128 && !s128_off) {
+      const dim3 g128((unsigned)(B * c.heads));
+      if (dh == 32) hipLaunchKernelGGL((enc_attention_s128_kernel<DT, 32>), g128, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+      else hipLaunchKernelGGL((enc_attention_s128_kernel<DT, 64>), g128, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+    } else
     if (dh == 32 && wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     else if (dh == 32) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     else if (wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
