@@ -542,7 +542,6 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   if (nq == 0) return MRAG_OK;
   if (!queries || !out_scores || !out_ids || !esize(q_dtype)) return fail(MRAG_ERR_INVALID, "bad buffer / dtype");
   if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "index has no centroids");
-  if (nq > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF call; batch the queries");
   MRAG_TRY(use_device(ix->device));
   hipStream_t stream = (hipStream_t)stream_;
   MRAG_TRY(ivf_finalize(ix, stream));
@@ -562,6 +561,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
       return MRAG_OK;   // (mrag_ivf_last_timing then reports the last chunk)
     }
   }
+  if (nq > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF batch (2^20); cut the query batch");
   ix->timed = false;
   MRAG_HIP(hipEventRecord(ix->ev[0], stream));
 
