@@ -946,7 +946,12 @@ static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM12
 
 template <int DT>
 static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M_pad, int epi, hipStream_t stream) {
-  if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && !g_force_gemm128) {
+  // 256 x 256 tiles only when they fill the chip: a small batch (the reference embeds one question, then candidates 50 at a
+  // time) leaves most CUs idle with 9-72 such tiles, the 128 x 128 kernel gives it four times the workgroups
+  static int n_cus = 0;
+  if (!n_cus) { hipDeviceProp_t pr; int dev = 0; n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  const bool fills = (int64_t)(M_pad / G2_T) * (l.N_pad / G2_T) >= n_cus / 2;
+  if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && fills && !g_force_gemm128) {
     typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int, int);
     const Fn fn = epi == EPI_BIAS ? (Fn)enc_gemm256_kernel<DT, EPI_BIAS> : epi == EPI_GELU ? (Fn)enc_gemm256_kernel<DT, EPI_GELU>
                                                                                           : (Fn)enc_gemm256_kernel<DT, EPI_RESID>;
