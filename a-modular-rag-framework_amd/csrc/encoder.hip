@@ -275,6 +275,84 @@ __global__ __launch_bounds__(GTHR) void enc_gemm_kernel(const uint16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------ skinny GEMM: <= 64 tokens (one question at a time)
+// The reference embeds ONE question per call (retrieval_backend.py:227): 16-64 tokens against 170 MB of weights.  With
+// 128 x 128 tiles that is 6-24 workgroups per GEMM, each walking K serially (12-48 K steps of one cold round trip each):
+// ~85 us per layer.  Here a workgroup owns 16 output columns and its four waves a QUARTER OF K each (fragments straight from
+// global memory into the MFMA operand layout, two 3-step chunks in flight), partial sums are added in LDS in wave order
+// (deterministic) and the epilogue stores 8-byte groups: N / 16 workgroups (48-192), a handful of round trips each.
+template <int DT, int EPI, int NFR>
+__global__ __launch_bounds__(256) void enc_gemm_skinny_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, const uint16_t* __restrict__ R,
+                                                              uint16_t* __restrict__ C, int N, int K) {
+  typedef typename EMfma<DT>::frag frag;
+  typedef typename EMfma<DT>::elem elem;
+  typedef elem e4 __attribute__((ext_vector_type(4)));
+  constexpr int CH = 3;                                   // K steps (of 32) per chunk; K / 128 is a multiple of 3 for every BERT width
+  __shared__ f32x4 part[4][NFR][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int n0 = blockIdx.x * 16;
+  const int ksw = K / 128;                                // K steps of this wave
+  const uint16_t* wp = W + (size_t)(n0 + i16) * K + (size_t)w * (K / 4) + g * 8;
+  const uint16_t* xp = X + (size_t)i16 * K + (size_t)w * (K / 4) + g * 8;
+  f32x4 acc[NFR];
+#pragma unroll
+  for (int nf = 0; nf < NFR; ++nf) acc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  frag a[2][CH], b[2][CH][NFR];
+  auto load = [&](int buf, int c) {
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      a[buf][s] = *(const frag*)(wp + (c * CH + s) * 32);
+#pragma unroll
+      for (int nf = 0; nf < NFR; ++nf) b[buf][s][nf] = *(const frag*)(xp + (size_t)nf * 16 * K + (c * CH + s) * 32);
+    }
+  };
+  const int nch = ksw / CH;
+  load(0, 0);
+#pragma unroll 1
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) load(1, c + 1);
+#pragma unroll
+    for (int s = 0; s < CH; ++s)
+#pragma unroll
+      for (int nf = 0; nf < NFR; ++nf) acc[nf] = EMfma<DT>::run(a[0][s], b[0][s][nf], acc[nf]);
+    if (c + 1 < nch) {
+      if (c + 2 < nch) load(0, c + 2);
+#pragma unroll
+      for (int s = 0; s < CH; ++s)
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) acc[nf] = EMfma<DT>::run(a[1][s], b[1][s][nf], acc[nf]);
+    }
+  }
+#pragma unroll
+  for (int nf = 0; nf < NFR; ++nf) part[w][nf][lane] = acc[nf];
+  __syncthreads();
+  // fragment nf is finished by wave nf % 4: partials added in wave order 0..3; lane holds columns n0 + 4 g + r of token 16 nf + i16
+  for (int nf = w; nf < NFR; nf += 4) {
+    f32x4 v = part[0][nf][lane];
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) { const f32x4 o = part[ww][nf][lane]; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+    const int n = n0 + 4 * g, token = nf * 16 + i16;
+    if (n >= N) continue;
+    const float4 bv = *(const float4*)(bias + n);
+    float o4[4] = {v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w};
+    if (EPI == EPI_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = gelu_erf(o4[r]);
+    }
+    if (EPI == EPI_RESID) {
+      const e4 rr = *(const e4*)(R + (size_t)token * N + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] += (float)rr[r];
+    }
+    e4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (elem)o4[r];
+    *(e4*)(C + (size_t)token * N + n) = o;
+  }
+}
+
 // ------------------------------------------------------------------ 256 x 256 persistent GEMM (the K2 main loop)
 // Used when N_pad % 256 == 0 and M_pad % 256 == 0.  Same structure as the similarity kernel of
 // bf_index.hip: 8 waves (2 x 4), 256 x 256 x 64 stages through LDS-DMA issued from inline asm (scalar
@@ -944,8 +1022,24 @@ static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hi
 static const int g_stagger_override = [] { const char* e = getenv("MRAG_ENC_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob
 static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM128"); return e && atoi(e) != 0; }();
 
+template <int DT, int NFR>
+static void launch_skinny(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int epi, hipStream_t stream) {
+  const dim3 grid((unsigned)(l.N_pad / 16)), block(256);
+  if (epi == EPI_BIAS) hipLaunchKernelGGL((enc_gemm_skinny_kernel<DT, EPI_BIAS, NFR>), grid, block, 0, stream, A, l.w, l.b, R, C, l.N, l.K);
+  else if (epi == EPI_GELU) hipLaunchKernelGGL((enc_gemm_skinny_kernel<DT, EPI_GELU, NFR>), grid, block, 0, stream, A, l.w, l.b, R, C, l.N, l.K);
+  else hipLaunchKernelGGL((enc_gemm_skinny_kernel<DT, EPI_RESID, NFR>), grid, block, 0, stream, A, l.w, l.b, R, C, l.N, l.K);
+}
+
 template <int DT>
-static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M_pad, int epi, hipStream_t stream) {
+static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint16_t* C, int M, int M_pad, int epi, hipStream_t stream) {
+  static const bool skinny_off = [] { const char* e = getenv("MRAG_ENC_NO_SKINNY"); return e && atoi(e) != 0; }();   // development switch (A/B)
+  if (M <= 64 && l.K % 384 == 0 && l.N % 4 == 0 && !skinny_off) {
+    if (M <= 16) launch_skinny<DT, 1>(A, l, R, C, epi, stream);
+    else if (M <= 32) launch_skinny<DT, 2>(A, l, R, C, epi, stream);
+    else launch_skinny<DT, 4>(A, l, R, C, epi, stream);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  }
   // 256 x 256 tiles only when they fill the chip: a small batch (the reference embeds one question, then candidates 50 at a
   // time) leaves most CUs idle with 9-72 such tiles, the 128 x 128 kernel gives it four times the workgroups
   static int n_cus = 0;
@@ -1011,7 +1105,7 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
   const dim3 agrid((unsigned)(B * c.heads * (wide_attn ? (S + 127) / 128 : 1)));
   for (int li = 0; li < c.layers; ++li) {
     Layer& L = e->layers[li];
-    MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, M_pad, EPI_BIAS, stream));
+    MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, (int)M, M_pad, EPI_BIAS, stream));
     const int32_t* am = (const int32_t*)e->mask.p;
     if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
     static const bool s128_off = [] { const char* e = getenv("MRAG_ENC_ATTN_GENERIC"); return e && atoi(e) != 0; }();   // development switch: A/B against the generic kernel
@@ -1025,10 +1119,10 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
     else if (wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     else hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     MRAG_HIP(hipGetLastError());
-    MRAG_TRY(run_gemm<DT>(ctx, L.attn_out, x, y, M_pad, EPI_RESID, stream));                    // y = ctx Wo + b + x
+    MRAG_TRY(run_gemm<DT>(ctx, L.attn_out, x, y, (int)M, M_pad, EPI_RESID, stream));                    // y = ctx Wo + b + x
     launch_ln<elem>((const elem*)y, M, H, L.ln1_g, L.ln1_b, c.layer_norm_eps, (elem*)x, tok_grid, tok_block, stream);
-    MRAG_TRY(run_gemm<DT>(x, L.ffn_in, nullptr, ffn, M_pad, EPI_GELU, stream));                  // ffn = gelu(x W1 + b1)
-    MRAG_TRY(run_gemm<DT>(ffn, L.ffn_out, x, y, M_pad, EPI_RESID, stream));                      // y = ffn W2 + b2 + x
+    MRAG_TRY(run_gemm<DT>(x, L.ffn_in, nullptr, ffn, (int)M, M_pad, EPI_GELU, stream));                  // ffn = gelu(x W1 + b1)
+    MRAG_TRY(run_gemm<DT>(ffn, L.ffn_out, x, y, (int)M, M_pad, EPI_RESID, stream));                      // y = ffn W2 + b2 + x
     launch_ln<elem>((const elem*)y, M, H, L.ln2_g, L.ln2_b, c.layer_norm_eps, (elem*)x, tok_grid, tok_block, stream);
     MRAG_HIP(hipGetLastError());
   }

@@ -67,6 +67,26 @@ def test_bge_base_shape_matches_oracle_cls():
     np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("arch,B,S,pool", [("minilm-l6", 1, 20, "mean"), ("minilm-l6", 2, 16, "mean"), ("minilm-l6", 3, 20, "mean"),
+                                            ("bge-base", 1, 24, "cls"), ("bge-base", 4, 16, "cls")])
+def test_single_question_batches_match_oracle(arch, B, S, pool):
+    """<= 64 tokens per call -- the reference embeds one question at a time (retrieval_backend.py:227): the skinny,
+    K-split GEMM path (csrc/encoder.hip enc_gemm_skinny_kernel), real layer widths."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec
+    spec = dict(oe.SPECS[arch], vocab_size=3000, max_position=64, layers=3)
+    w = oe.seeded_weights(spec, 12)
+    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=64)), w)
+    ids, mask = _batch(spec, B, S, 13)
+    got = enc.forward(ids, mask, pool=pool)
+    want = oe.forward(spec, w, ids, mask, pool=pool)
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+    # the same rows inside a larger batch (tiled GEMM path) agree to fp16-activation noise
+    ids2, mask2 = _batch(spec, 40, S, 14)
+    ids2[:B], mask2[:B] = ids, mask
+    big = enc.forward(ids2, mask2, pool=pool)
+    np.testing.assert_allclose(big[:B], got, rtol=0, atol=TOL)
+
+
 @pytest.mark.parametrize("case", ["minilm2", "bge1"])
 def test_f6_hf_golden(golden_dir, case):
     """F6: the committed HF BertModel outputs (tests/golden/make_golden_encoder.py) -- MiniLM-L6 / bge-base layer
