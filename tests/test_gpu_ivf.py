@@ -198,3 +198,23 @@ def test_bf16_storage_and_exact_integer_ties():
         rv, ri = ds.ivf_search(qi, ci, ceni, a, npb, kk)
         assert np.array_equal(ids, ri), (kk, npb)
         assert np.array_equal(sc, rv.astype(np.float32))
+
+
+def test_many_probes_and_odd_dim():
+    """nprobe = 200 of 512 lists (the probe selection then keeps 200 of 512 per query, the selection walks 200 segments),
+    a dimension that is not a multiple of 64, single-query and single-probe calls."""
+    from mrag_amd.index import IVFFlatIndex
+    n, nq, d, nlist = 40000, 70, 100, 512
+    rows, qs = ds.make_clustered(n, nq, d, 51, n_centroids=256)
+    c16, q16 = ds.normalize_round(rows), ds.normalize_round(qs)
+    cen = ds.kmeans_spherical(c16, nlist, 2, seed=6)
+    ix = IVFFlatIndex(d, nlist)
+    ix.set_centroids(cen, normalize=False)
+    ix.add(c16, normalize=False)
+    a = ix.assignments().astype(np.int64)
+    for k, nprobe, sl in ((10, 200, slice(0, nq)), (64, 33, slice(0, nq)), (5, 1, slice(0, 1)), (1, 200, slice(3, 4))):
+        sc, ids = ix.search(q16[sl], k, nprobe, normalize=False)
+        rv, ri = ds.ivf_search(q16[sl], c16, cen, a, nprobe, k)
+        np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+        strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
+        assert bad <= max(1, int(0.003 * sc.size)), (k, nprobe, strict, bad)
