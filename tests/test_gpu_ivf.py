@@ -218,3 +218,32 @@ def test_many_probes_and_odd_dim():
         np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
         strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
         assert bad <= max(1, int(0.003 * sc.size)), (k, nprobe, strict, bad)
+
+
+def test_randomised_shapes_against_oracle():
+    """24 seeded random (rows, lists, dim, queries, k, nprobe) combinations -- list lengths around the 128-row tile and the
+    4 / 8 / 16-row granules of the scan, query groups around 128, k up to 64 -- against the oracle."""
+    from mrag_amd.index import IVFFlatIndex
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        nlist = int(rng.choice([3, 8, 17, 40, 64]))
+        n = int(rng.integers(nlist * 20, nlist * 400))
+        d = int(rng.choice([32, 64, 96, 160]))
+        nq = int(rng.choice([1, 7, 127, 128, 129, 300]))
+        k = int(rng.choice([1, 3, 10, 33, 64]))
+        nprobe = int(rng.integers(1, nlist + 1))
+        rows, qs = ds.make_clustered(n, nq, d, 100 + case, n_centroids=max(2, nlist // 2))
+        c16, q16 = ds.normalize_round(rows), ds.normalize_round(qs)
+        cen = ds.kmeans_spherical(c16, nlist, 2, seed=case)
+        ix = IVFFlatIndex(d, nlist)
+        ix.set_centroids(cen, normalize=False)
+        ix.add(c16, normalize=False)
+        a = ix.assignments().astype(np.int64)
+        sc, ids = ix.search(q16, k, nprobe, normalize=False)
+        rv, ri = ds.ivf_search(q16, c16, cen, a, nprobe, k)
+        fin = np.isfinite(rv)
+        assert np.array_equal(np.isfinite(sc), fin), (case, n, nlist, d, nq, k, nprobe)
+        np.testing.assert_allclose(sc[fin], rv[fin], rtol=0, atol=1e-5, err_msg=str((case, n, nlist, d, nq, k, nprobe)))
+        strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
+        assert bad <= max(1, int(0.004 * sc.size)), (case, n, nlist, d, nq, k, nprobe, strict, bad)
+        ix.close()
