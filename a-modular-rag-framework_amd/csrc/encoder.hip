@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64 * NW) void enc_attention_kernel(const uint16_t* 
   }
 }
 
-// ------------------------------------------------------------------ attention, sequences of <= 128 tokens
+// ------------------------------------------------------------------ attention, sequences of <= 256 tokens
 // One workgroup (4 waves) per (batch, head): K and V of the head are staged ONCE, row-major, with all global loads in flight
 // together; every wave then owns 32 query rows (two 16-row MFMA groups) against all 128 (padded) keys -- no key-block loop, no
 // online-softmax rescaling, no per-block barriers.  The two operands whose contraction index runs along LDS ROWS come from
@@ -774,30 +774,38 @@ __device__ __forceinline__ float row16_sum(float x) {
   x += dpp_ror16<8>(x); x += dpp_ror16<4>(x); x += dpp_ror16<2>(x); return x + dpp_ror16<1>(x);
 }
 
-template <int DT, int DH>
-__global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-                                                                 uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
+// SP = padded key count (64 / 128 / 256), NW waves; every wave owns SP / NW query rows (groups of 16).
+template <int DT, int DH, int SP, int NW>
+__global__ __launch_bounds__(64 * NW) void enc_attention_s128_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+                                                                     uint16_t* __restrict__ out, int B, int S, int H, int heads, float scale) {
   typedef typename EMfma<DT>::frag frag;
   typedef typename EMfma<DT>::elem elem;
   typedef elem e4 __attribute__((ext_vector_type(4)));
-  constexpr int SP = 128;                      // keys, padded
+  constexpr int NT_ = 64 * NW;
   constexpr int NK = DH / 32;                  // k steps of Q K^T
   constexpr int ND = DH / 16;                  // 16-column groups of the output
+  constexpr int NFK = SP / 16;                 // 16-key groups
+  constexpr int KS = SP / 32;                  // k steps of P V
+  constexpr int GROUPS = SP / (NW * 16);       // 16-row groups per wave
+  constexpr bool HOIST = KS * ND <= 16;        // V fragments kept in registers across the wave's row groups (<= 64 VGPRs)
   constexpr int KP = DH + 8;                   // row pitch of the K / V images (elements): 16-byte pad
   constexpr int PIECES = DH / 8;               // 16-byte pieces per row
+  constexpr int LOADS = SP * PIECES / NT_;
   __shared__ __attribute__((aligned(16))) elem sK[SP][KP];
   __shared__ __attribute__((aligned(16))) elem sV[SP][KP];
-  __shared__ __attribute__((aligned(16))) elem sPt[4][SP][16];     // per wave: P^T [key][query row]; afterwards its [16][DH] output slab
+  __shared__ __attribute__((aligned(16))) elem sPt[NW][SP][16];    // per wave: P^T [key][query row]; afterwards its [16][DH] output slab
   __shared__ float sBias[SP];
+  constexpr int SLP = SP >= KP ? KP : DH;      // row pitch of the output slab inside the wave's P^T area (SP x 16 elements)
+  static_assert(SP * 16 >= 16 * SLP, "output slab must fit the wave's P^T area");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int hh = blockIdx.x % heads, bb = blockIdx.x / heads;
   const size_t ld = (size_t)3 * H;
   const uint16_t* base = qkv + (size_t)bb * S * ld;
   {
-    frag kv[SP * PIECES / 256], vv[SP * PIECES / 256];
+    frag kv[LOADS], vv[LOADS];
 #pragma unroll
-    for (int i = 0; i < SP * PIECES / 256; ++i) {
-      const int e = tid + i * 256, key = e / PIECES, c = e % PIECES;
+    for (int i = 0; i < LOADS; ++i) {
+      const int e = tid + i * NT_, key = e / PIECES, c = e % PIECES;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { kv[i][j] = (elem)0.f; vv[i][j] = (elem)0.f; }
       if (key < S) {
@@ -806,28 +814,31 @@ __global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t*
       }
     }
 #pragma unroll
-    for (int i = 0; i < SP * PIECES / 256; ++i) {
-      const int e = tid + i * 256, key = e / PIECES, c = e % PIECES;
+    for (int i = 0; i < LOADS; ++i) {
+      const int e = tid + i * NT_, key = e / PIECES, c = e % PIECES;
       *(frag*)&sK[key][c * 8] = kv[i];
       *(frag*)&sV[key][c * 8] = vv[i];
     }
   }
-  if (tid < SP) sBias[tid] = (tid < S && mask[(size_t)bb * S + tid] != 0) ? 0.f : -1e30f;
+  for (int i = tid; i < SP; i += NT_) sBias[i] = (i < S && mask[(size_t)bb * S + i] != 0) ? 0.f : -1e30f;
   __syncthreads();
   const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;   // tr read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
-  // V fragments, shared by the wave's two row groups: vf[ks][d] = V[keys 32 ks + 8 g .. +7][dh 16 d + i16]
-  frag vf[4][ND];
+  auto v_frag = [&](int ks, int d) -> frag {     // V[keys 32 ks + 8 g .. +7][dh 16 d + i16]
+    return tr_read_pair<frag>(&sV[ks * 32 + 8 * g + tq][d * 16 + 4 * tp], &sV[ks * 32 + 8 * g + 4 + tq][d * 16 + 4 * tp]);
+  };
+  frag vf[HOIST ? KS : 1][ND];
+  if (HOIST) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
-      vf[ks][d] = tr_read_pair<frag>(&sV[ks * 32 + 8 * g + tq][d * 16 + 4 * tp], &sV[ks * 32 + 8 * g + 4 + tq][d * 16 + 4 * tp]);
-  float bias[8];
+      for (int d = 0; d < ND; ++d) vf[ks][d] = v_frag(ks, d);
+  }
+  float bias[NFK];
 #pragma unroll
-  for (int nf = 0; nf < 8; ++nf) bias[nf] = sBias[nf * 16 + i16];
+  for (int nf = 0; nf < NFK; ++nf) bias[nf] = sBias[nf * 16 + i16];
 #pragma unroll 1
-  for (int rg = 0; rg < 2; ++rg) {
-    const int row0 = w * 32 + rg * 16;
+  for (int rg = 0; rg < GROUPS; ++rg) {
+    const int row0 = (w * GROUPS + rg) * 16;
     if (row0 >= S) break;                                                  // (wave-uniform)
     const int q_row = row0 + i16;
     frag qf[NK];
@@ -840,9 +851,9 @@ __global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t*
       qf[ks] = z;
     }
     // scores: lane holds rows 4 g + r, key 16 nf + i16
-    f32x4 sc[8];
+    f32x4 sc[NFK];
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf) {
+    for (int nf = 0; nf < NFK; ++nf) {
       sc[nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
@@ -855,16 +866,16 @@ __global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t*
     for (int r = 0; r < 4; ++r) {
       float mx = -1e30f;
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) { sc[nf][r] = sc[nf][r] * scale + bias[nf]; mx = fmaxf(mx, sc[nf][r]); }
+      for (int nf = 0; nf < NFK; ++nf) { sc[nf][r] = sc[nf][r] * scale + bias[nf]; mx = fmaxf(mx, sc[nf][r]); }
       mx = row16_max(mx);
       float rs = 0.f;
 #pragma unroll
-      for (int nf = 0; nf < 8; ++nf) { const float e = __expf(sc[nf][r] - mx); sc[nf][r] = e; rs += e; }
+      for (int nf = 0; nf < NFK; ++nf) { const float e = __expf(sc[nf][r] - mx); sc[nf][r] = e; rs += e; }
       inv[r] = 1.0f / row16_sum(rs);
     }
     // P^T -> LDS: one 8-byte store per accumulator (4 consecutive query rows of one key)
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf) {
+    for (int nf = 0; nf < NFK; ++nf) {
       e4 pk;
 #pragma unroll
       for (int r = 0; r < 4; ++r) pk[r] = (elem)sc[nf][r];
@@ -876,10 +887,10 @@ __global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t*
 #pragma unroll
     for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const frag pf = tr_read_pair<frag>(&sPt[w][ks * 32 + 8 * g + tq][4 * tp], &sPt[w][ks * 32 + 8 * g + 4 + tq][4 * tp]);
 #pragma unroll
-      for (int d = 0; d < ND; ++d) o[d] = EMfma<DT>::run(pf, vf[ks][d], o[d]);
+      for (int d = 0; d < ND; ++d) o[d] = EMfma<DT>::run(pf, HOIST ? vf[HOIST ? ks : 0][d] : v_frag(ks, d), o[d]);
     }
     // out[row][hh*DH + 16 d + i16], row = row0 + 4 g + r: through the wave's (now idle) P^T area as a [16][DH] slab, so that it
     // leaves as 16-byte pieces of whole rows
@@ -889,13 +900,13 @@ __global__ __launch_bounds__(256) void enc_attention_s128_kernel(const uint16_t*
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int d = 0; d < ND; ++d) slab[(4 * g + r) * KP + d * 16 + i16] = (elem)(o[d][r] * inv[r]);
+      for (int d = 0; d < ND; ++d) slab[(4 * g + r) * SLP + d * 16 + i16] = (elem)(o[d][r] * inv[r]);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < 16 * PIECES; e += 64) {
       const int rr = e / PIECES, pc = e % PIECES;
       const int row = row0 + rr;
-      if (row < S) *(frag*)&out[((size_t)bb * S + row) * H + hh * DH + pc * 8] = *(const frag*)&slab[rr * KP + pc * 8];
+      if (row < S) *(frag*)&out[((size_t)bb * S + row) * H + hh * DH + pc * 8] = *(const frag*)&slab[rr * SLP + pc * 8];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -1109,10 +1120,13 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
     const int32_t* am = (const int32_t*)e->mask.p;
     if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
     static const bool s128_off = [] { const char* e = getenv("MRAG_ENC_ATTN_GENERIC"); return e && atoi(e) != 0; }();   // development switch: A/B against the generic kernel
-    if (S <= 128 && !s128_off) {
+    if (S <= 256 && !s128_off) {
+      // whole-sequence kernel: K / V of a head staged once, keys padded to 64 / 128 / 256
       const dim3 g128((unsigned)(B * c.heads));
-      if (dh == 32) hipLaunchKernelGGL((enc_attention_s128_kernel<DT, 32>), g128, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
-      else hipLaunchKernelGGL((enc_attention_s128_kernel<DT, 64>), g128, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
+#define MRAG_ATTN(DHV, SPV, NWV) hipLaunchKernelGGL((enc_attention_s128_kernel<DT, DHV, SPV, NWV>), g128, dim3(64 * NWV), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale)
+      if (dh == 32) { if (S <= 64) MRAG_ATTN(32, 64, 4); else if (S <= 128) MRAG_ATTN(32, 128, 4); else MRAG_ATTN(32, 256, 8); }
+      else { if (S <= 64) MRAG_ATTN(64, 64, 4); else if (S <= 128) MRAG_ATTN(64, 128, 4); else MRAG_ATTN(64, 256, 8); }
+#undef MRAG_ATTN
     } else
     if (dh == 32 && wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     else if (dh == 32) hipLaunchKernelGGL((enc_attention_kernel<DT, 32, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
