@@ -379,11 +379,26 @@ constexpr int G2_BUF1 = G2_STAGE + G2_PAD;            // epilogue's 128 x 528-by
 constexpr int G2_LDS = 2 * G2_STAGE + G2_PAD;         // 132 KiB
 constexpr int G2_CPITCH = 528;                        // output row pitch in LDS: 256 columns x 2 B + 16 (bank shift per row)
 
-template <int DT, int EPI>
+// LayerNorm folded into the GEMMs around it (LNF flags; forward_impl, "fused LayerNorm" flow):
+//   1 LNA   the A operand is the PRE-LayerNorm tensor y and W holds gamma-scaled weights W' = gamma o W:
+//           out = rstd_t (y W'^T - mu_t s_n) + c_n   with s_n = sum_k W'[n][k], c_n = b_n + sum_k beta_k W[n][k] (in `bias`)
+//   2 LNR   the residual R is a pre-LayerNorm tensor: the epilogue adds (R - mu_t) rstd_t gamma_n (beta is folded into `bias`)
+//   4 STATS the epilogue also emits, per token, partial (sum, sum of squares) of the values it stores (as rounded)
+// so that a LayerNorm between two GEMMs never makes its own pass over HBM (2 x 0.8 GB per layer at H = 768).
+struct LnArgs {
+  const float* a_stats;   // LNA: (mu, rstd) per token
+  const float* s_vec;     // LNA: s_n per output column
+  const float* r_stats;   // LNR: (mu, rstd) per token of the residual's LayerNorm
+  const float* r_gamma;   // LNR: its gamma
+  float* partials;        // STATS: [token][np][2]
+  int np;                 // STATS: partial slots per token = 2 x column tiles
+};
+
+template <int DT, int EPI, int LNF>
 __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                                 const float* __restrict__ bias, const uint16_t* __restrict__ R,
                                                                 uint16_t* __restrict__ C, int N, int K, int tiles_m, int tiles_n,
-                                                                int stagger) {
+                                                                int stagger, LnArgs ln) {
   typedef typename EMfma<DT>::frag frag;
   typedef typename EMfma<DT>::elem elem;
   typedef elem e4 __attribute__((ext_vector_type(4)));
@@ -539,13 +554,29 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
     // passes, hipcc puts an s_waitcnt vmcnt(0) behind each of them (8 bias + 32 residual loads = up to 40 serial
     // L2 round trips per tile), and in pass 1 that wait also sits out pass 0's stores (vmcnt counts in order).
     float4 bv[8];
-    e4 rr[8][4];
+    float4 xv[(LNF & 3) ? 8 : 1];               // LNA: s_n; LNR: gamma_n
+    e4 rr[8][(LNF & 2) ? 2 : 4];                // (LNR: the residual is loaded pass by pass -- the register budget)
+    float2 tst[(LNF & 3) ? 4 : 1];              // (mu, rstd) of this lane's four tokens
+    float ps1[(LNF & 4) ? 4 : 1], ps2[(LNF & 4) ? 4 : 1];
+    if (LNF & 3) {
+      const float2* st = (const float2*)((LNF & 1) ? ln.a_stats : ln.r_stats);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) tst[nf] = st[t_b + nf * 16];
+    }
+    if (LNF & 4) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) { ps1[nf] = 0.f; ps2[nf] = 0.f; }
+    }
 #pragma unroll
     for (int mf = 0; mf < 8; ++mf) {
       const int n0 = n_b + mf * 16;
       bv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n0 < N && !ENC_DBG(8)) bv[mf] = *(const float4*)(bias + n0);
-      if (EPI == EPI_RESID && !ENC_DBG(8)) {
+      if (LNF & 3) {
+        xv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 < N) xv[mf] = *(const float4*)(((LNF & 1) ? ln.s_vec : ln.r_gamma) + n0);
+      }
+      if (EPI == EPI_RESID && !(LNF & 2) && !ENC_DBG(8)) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           rr[mf][nf] = (e4){(elem)0.f, (elem)0.f, (elem)0.f, (elem)0.f};
@@ -557,23 +588,53 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      if (LNF & 2) {   // this pass's residual rows, all loads back to back
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) {
+          const int n0 = n_b + mf * 16;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            rr[mf][h] = (e4){(elem)0.f, (elem)0.f, (elem)0.f, (elem)0.f};
+            if (n0 < N) rr[mf][h] = *(const e4*)(R + (size_t)(t_b + (pass * 2 + h) * 16) * N + n0);
+          }
+        }
+      }
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int nf = pass * 2 + h;
-          float v[4] = {acc[mf][nf][0] + bv[mf].x, acc[mf][nf][1] + bv[mf].y, acc[mf][nf][2] + bv[mf].z, acc[mf][nf][3] + bv[mf].w};
+          const float bq[4] = {bv[mf].x, bv[mf].y, bv[mf].z, bv[mf].w};
+          float v[4];
+          if (LNF & 1) {
+            const float xq[4] = {xv[mf].x, xv[mf].y, xv[mf].z, xv[mf].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tst[nf].y * (acc[mf][nf][r] - tst[nf].x * xq[r]) + bq[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + bq[r];
+          }
           if (EPI == EPI_GELU && !ENC_DBG(4)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
           }
           if (EPI == EPI_RESID && !ENC_DBG(8)) {
+            if (LNF & 2) {
+              const float xq[4] = {xv[mf].x, xv[mf].y, xv[mf].z, xv[mf].w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rr[mf][nf][r];
+              for (int r = 0; r < 4; ++r) v[r] += ((float)rr[mf][h][r] - tst[nf].x) * tst[nf].y * xq[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)rr[mf][nf][r];
+            }
           }
           e4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (elem)v[r];
+          if ((LNF & 4) && n_b + mf * 16 < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; ps1[nf] += f; ps2[nf] += f * f; }
+          }
           const int tl = wn * 32 + h * 16 + (lane & 15);    // token row inside the pass
           *(e4*)(slab + tl * G2_CPITCH + (n_l + mf * 16) * 2) = o;
         }
@@ -603,7 +664,54 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+    if (LNF & 4) {
+      // the four lane groups (lane >> 4) of a wave hold different columns of the SAME tokens: add them up, then one lane per
+      // token writes the wave's partial -- slot 2 tn + wm of the token (finalised by enc_ln_stats_kernel in slot order)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        ps1[nf] += __shfl_xor(ps1[nf], 16); ps1[nf] += __shfl_xor(ps1[nf], 32);
+        ps2[nf] += __shfl_xor(ps2[nf], 16); ps2[nf] += __shfl_xor(ps2[nf], 32);
+        if (lane < 16) ((float2*)ln.partials)[(size_t)(t_b + nf * 16) * ln.np + 2 * tn + wm] = make_float2(ps1[nf], ps2[nf]);
+      }
+    }
   }
+}
+
+// (mu, rstd) per token from the partial sums of the producing GEMM (fixed slot order: deterministic)
+__global__ void enc_ln_stats_kernel(const float2* __restrict__ partials, int np, int64_t n_tok, int H, float eps, float2* __restrict__ stats) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tok) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < np; ++i) { const float2 p = partials[t * np + i]; s1 += p.x; s2 += p.y; }
+  const float mean = s1 / H;
+  const float var = fmaxf(s2 / H - mean * mean, 0.f);
+  stats[t] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+// LayerNorm folded into the Linear that consumes it: Wf = round(gamma o W), s_n = sum_k Wf[n][k], c_n = b_n + sum_k beta_k W[n][k].
+// One wave per output row.
+template <typename E>
+__global__ __launch_bounds__(256) void enc_fold_ln_kernel(const E* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int N, int K, E* __restrict__ Wf,
+                                                          float* __restrict__ c, float* __restrict__ svec) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f, cb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = (float)W[(size_t)n * K + k];
+    const E wf = (E)(gamma[k] * w);
+    Wf[(size_t)n * K + k] = wf;
+    s += (float)wf;
+    cb += beta[k] * w;
+  }
+  s = wave_sum(s); cb = wave_sum(cb);
+  if (lane == 0) { svec[n] = s; c[n] = b[n] + cb; }
+}
+
+__global__ void enc_add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
 }
 
 // ------------------------------------------------------------------ attention
@@ -958,6 +1066,10 @@ struct Linear {
 struct Layer {
   Linear qkv, attn_out, ffn_in, ffn_out;
   float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+  // fused-LayerNorm flow (built lazily by fold_layernorms): the Linears that CONSUME a LayerNorm with gamma folded into the
+  // weights (c_n in .b, s_n beside it), and the biases of the Linears whose RESIDUAL is a LayerNorm output with its beta added
+  Linear qkv_f, ffn_in_f;
+  float *qkv_s = nullptr, *ffn_in_s = nullptr, *attn_out_bf = nullptr, *ffn_out_bf = nullptr;
 };
 
 struct Encoder : Object {
@@ -967,12 +1079,14 @@ struct Encoder : Object {
   std::map<std::string, bool> have;
   std::vector<void*> allocs;
   DevBuf ids, mask, x, y, qkv, ctx, ffn, out, stage;
+  DevBuf y2, partials, st1, st2;           // fused-LayerNorm flow: second pre-LayerNorm buffer, partial sums, (mu, rstd) per token
+  bool folded = false;                     // fold_layernorms done for the current parameters
   hipEvent_t ev[2] = {nullptr, nullptr};   // device work of the last forward (embeddings .. pooling), on its stream
   bool timed = false;
   ~Encoder() override {
     for (auto& v : ev) if (v) (void)hipEventDestroy(v);
     for (void* p : allocs) (void)hipFree(p);
-    for (DevBuf* b : {&ids, &mask, &x, &y, &qkv, &ctx, &ffn, &out, &stage}) b->release();
+    for (DevBuf* b : {&ids, &mask, &x, &y, &qkv, &ctx, &ffn, &out, &stage, &y2, &partials, &st1, &st2}) b->release();
   }
 };
 
@@ -1057,9 +1171,9 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
   if (!n_cus) { hipDeviceProp_t pr; int dev = 0; n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
   const bool fills = (int64_t)(M_pad / G2_T) * (l.N_pad / G2_T) >= n_cus / 2;
   if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && fills && !g_force_gemm128) {
-    typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int, int);
-    const Fn fn = epi == EPI_BIAS ? (Fn)enc_gemm256_kernel<DT, EPI_BIAS> : epi == EPI_GELU ? (Fn)enc_gemm256_kernel<DT, EPI_GELU>
-                                                                                          : (Fn)enc_gemm256_kernel<DT, EPI_RESID>;
+    typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int, int, LnArgs);
+    const Fn fn = epi == EPI_BIAS ? (Fn)enc_gemm256_kernel<DT, EPI_BIAS, 0> : epi == EPI_GELU ? (Fn)enc_gemm256_kernel<DT, EPI_GELU, 0>
+                                                                                             : (Fn)enc_gemm256_kernel<DT, EPI_RESID, 0>;
     static std::map<const void*, bool> attr_done;
     if (!attr_done[(const void*)fn]) {
       MRAG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
@@ -1076,7 +1190,7 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
     int stagger = 0;
     (void)per_wg;
     if (g_stagger_override != 0) stagger = (nwg % 8 == 0) ? g_stagger_override : 0;
-    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2, stagger);
+    hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, l.w, l.b, R, C, l.N, l.K, tm2, tn2, stagger, LnArgs{});
     MRAG_HIP(hipGetLastError());
     return MRAG_OK;
   }
@@ -1086,6 +1200,60 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
   else if (epi == EPI_GELU) hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_GELU>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
   else hipLaunchKernelGGL((enc_gemm_kernel<DT, EPI_RESID>), grid, block, 0, stream, A, l.w, l.b, R, C, M_pad, l.N, l.K, tiles_n);
   MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
+// 256 x 256 GEMM of the fused-LayerNorm flow: weights / bias given explicitly (folded or plain), LNF = LnArgs flags
+template <int DT, int EPI, int LNF>
+static int run_gemm_ln(const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* R, uint16_t* C, int N, int N_pad, int K,
+                       int M_pad, const LnArgs& ln, hipStream_t stream) {
+  const void* fn = (const void*)enc_gemm256_kernel<DT, EPI, LNF>;
+  static bool attr_done = false;
+  if (!attr_done) { MRAG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS)); attr_done = true; }
+  const int tm2 = M_pad / G2_T, tn2 = N_pad / G2_T;
+  int cus = 256;
+  { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+  const int nwg = std::min(tm2 * tn2, cus);
+  hipLaunchKernelGGL((enc_gemm256_kernel<DT, EPI, LNF>), dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, W, bias, R, C, N, K, tm2, tn2, 0, ln);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
+// gamma-scaled weights, s / c vectors and beta-augmented biases of the fused-LayerNorm flow, from the plain parameters
+template <int DT>
+static int fold_layernorms(Encoder* e, hipStream_t stream) {
+  typedef typename EMfma<DT>::elem elem;
+  const mrag_encoder_config& c = e->cfg;
+  const int H = c.hidden;
+  auto fold = [&](const Linear& src, Linear& dst, float*& svec, const float* g, const float* b) -> int {
+    if (!dst.w) {
+      dst.N = src.N; dst.K = src.K; dst.N_pad = src.N_pad;
+      MRAG_TRY(dev_alloc(e, (void**)&dst.w, (size_t)dst.N_pad * dst.K * 2));
+      MRAG_TRY(dev_alloc(e, (void**)&dst.b, (size_t)dst.N_pad * 4));
+      MRAG_TRY(dev_alloc(e, (void**)&svec, (size_t)dst.N_pad * 4));
+    }
+    hipLaunchKernelGGL((enc_fold_ln_kernel<elem>), dim3((unsigned)((src.N + 3) / 4)), dim3(256), 0, stream, (const elem*)src.w, src.b, g, b,
+                       src.N, src.K, (elem*)dst.w, dst.b, svec);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  };
+  auto add = [&](const float* bias, const float* beta, float*& out) -> int {
+    if (!out) MRAG_TRY(dev_alloc(e, (void**)&out, (size_t)round_up(H, G2_T) * 4));
+    hipLaunchKernelGGL(enc_add_vec_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, bias, beta, H, out);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  };
+  for (int li = 0; li < c.layers; ++li) {
+    Layer& L = e->layers[li];
+    MRAG_TRY(fold(L.ffn_in, L.ffn_in_f, L.ffn_in_s, L.ln1_g, L.ln1_b));
+    MRAG_TRY(add(L.ffn_out.b, L.ln1_b, L.ffn_out_bf));
+    if (li > 0) {
+      Layer& P = e->layers[li - 1];
+      MRAG_TRY(fold(L.qkv, L.qkv_f, L.qkv_s, P.ln2_g, P.ln2_b));
+      MRAG_TRY(add(L.attn_out.b, P.ln2_b, L.attn_out_bf));
+    }
+  }
+  e->folded = true;
   return MRAG_OK;
 }
 
@@ -1114,8 +1282,39 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
   const float scale = 1.0f / sqrtf((float)dh);
   const bool wide_attn = S > 64;
   const dim3 agrid((unsigned)(B * c.heads * (wide_attn ? (S + 127) / 128 : 1)));
+  // Fused-LayerNorm flow (large batches: every GEMM of a layer on the 256 x 256 kernel): the two LayerNorms of a layer never
+  // run as kernels -- the GEMM before one emits per-token partial sums, a tiny kernel turns them into (mu, rstd), and the GEMMs
+  // after it take the PRE-LayerNorm tensor as operand / residual (LnArgs above).  Only the last layer's output LayerNorm is
+  // materialised, for the pooling.  MRAG_ENC_NO_FUSED_LN=1 keeps the plain flow (A/B, and the path small batches always take).
+  static const bool fused_off = [] { const char* v = getenv("MRAG_ENC_NO_FUSED_LN"); return v && atoi(v) != 0; }();
+  static int n_cus_f = 0;
+  if (!n_cus_f) { hipDeviceProp_t pr; int dev = 0; n_cus_f = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  const bool fused = !fused_off && !g_force_gemm128 && M_pad % G2_T == 0 && H % 16 == 0 && round_up(H, G2_T) / G2_T * (M_pad / G2_T) >= n_cus_f / 2;
+  uint16_t *y1 = y, *y2 = nullptr;
+  float2 *st1 = nullptr, *st2 = nullptr;
+  float* partials = nullptr;
+  const int np = 2 * (int)(round_up(H, G2_T) / G2_T);
+  if (fused) {
+    if (!e->folded) MRAG_TRY(fold_layernorms<DT>(e, stream));
+    MRAG_TRY(e->y2.ensure((size_t)M_pad * H * 2));
+    MRAG_TRY(e->partials.ensure((size_t)M_pad * np * 8));
+    MRAG_TRY(e->st1.ensure((size_t)M_pad * 8));
+    MRAG_TRY(e->st2.ensure((size_t)M_pad * 8));
+    y2 = (uint16_t*)e->y2.p; st1 = (float2*)e->st1.p; st2 = (float2*)e->st2.p; partials = (float*)e->partials.p;
+  }
+  const int H_pad = (int)round_up(H, G2_T), I_pad = (int)round_up(I, G2_T), Q_pad = (int)round_up(3 * H, G2_T);
+  auto finalize_stats = [&](float2* st) -> int {
+    hipLaunchKernelGGL(enc_ln_stats_kernel, dim3((unsigned)((M_pad + 255) / 256)), dim3(256), 0, stream, (const float2*)partials, np, (int64_t)M_pad, H,
+                       c.layer_norm_eps, st);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  };
   for (int li = 0; li < c.layers; ++li) {
     Layer& L = e->layers[li];
+    if (fused && li > 0) {
+      LnArgs a{}; a.a_stats = (const float*)st2; a.s_vec = L.qkv_s;
+      MRAG_TRY((run_gemm_ln<DT, EPI_BIAS, 1>(y2, L.qkv_f.w, L.qkv_f.b, nullptr, qkv, 3 * H, Q_pad, H, M_pad, a, stream)));
+    } else
     MRAG_TRY(run_gemm<DT>(x, L.qkv, nullptr, qkv, (int)M, M_pad, EPI_BIAS, stream));
     const int32_t* am = (const int32_t*)e->mask.p;
     if (dh != 32 && dh != 64) return fail(MRAG_ERR_UNSUPPORTED, "head dim %d not supported (32 or 64)", dh);
@@ -1133,6 +1332,25 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
     else if (wide_attn) hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 8>), agrid, dim3(512), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     else hipLaunchKernelGGL((enc_attention_kernel<DT, 64, 4>), agrid, dim3(256), 0, stream, qkv, am, ctx, B, S, H, c.heads, scale);
     MRAG_HIP(hipGetLastError());
+    if (fused) {
+      LnArgs a{}; a.partials = partials; a.np = np;
+      if (li == 0) {                                                       // y1 = ctx Wo + b + x                      (+ stats of y1)
+        MRAG_TRY((run_gemm_ln<DT, EPI_RESID, 4>(ctx, L.attn_out.w, L.attn_out.b, x, y1, H, H_pad, H, M_pad, a, stream)));
+      } else {                                                             // y1 = ctx Wo + (b + beta2') + LN2'(y2)     (+ stats)
+        a.r_stats = (const float*)st2; a.r_gamma = e->layers[li - 1].ln2_g;
+        MRAG_TRY((run_gemm_ln<DT, EPI_RESID, 6>(ctx, L.attn_out.w, L.attn_out_bf, y2, y1, H, H_pad, H, M_pad, a, stream)));
+      }
+      MRAG_TRY(finalize_stats(st1));
+      LnArgs f{}; f.a_stats = (const float*)st1; f.s_vec = L.ffn_in_s;     // ffn = gelu(LN1(y1) W1 + b1), LN1 folded
+      MRAG_TRY((run_gemm_ln<DT, EPI_GELU, 1>(y1, L.ffn_in_f.w, L.ffn_in_f.b, nullptr, ffn, I, I_pad, H, M_pad, f, stream)));
+      LnArgs d{}; d.partials = partials; d.np = np; d.r_stats = (const float*)st1; d.r_gamma = L.ln1_g;
+      MRAG_TRY((run_gemm_ln<DT, EPI_RESID, 6>(ffn, L.ffn_out.w, L.ffn_out_bf, y1, y2, H, H_pad, I, M_pad, d, stream)));   // y2 = ffn W2 + (b2 + beta1) + LN1(y1)
+      MRAG_TRY(finalize_stats(st2));
+      if (li + 1 == c.layers)                                              // the encoder's output: the one LayerNorm that is materialised
+        launch_ln<elem>((const elem*)y2, M, H, L.ln2_g, L.ln2_b, c.layer_norm_eps, (elem*)x, tok_grid, tok_block, stream);
+      MRAG_HIP(hipGetLastError());
+      continue;
+    }
     MRAG_TRY(run_gemm<DT>(ctx, L.attn_out, x, y, (int)M, M_pad, EPI_RESID, stream));                    // y = ctx Wo + b + x
     launch_ln<elem>((const elem*)y, M, H, L.ln1_g, L.ln1_b, c.layer_norm_eps, (elem*)x, tok_grid, tok_block, stream);
     MRAG_TRY(run_gemm<DT>(x, L.ffn_in, nullptr, ffn, (int)M, M_pad, EPI_GELU, stream));                  // ffn = gelu(x W1 + b1)
@@ -1245,7 +1463,7 @@ int mrag_encoder_set_param(mrag_handle h, const char* name, const float* data, i
   } else {
     return fail(MRAG_ERR_INVALID, "unknown parameter %s", name);
   }
-  if (st == MRAG_OK) e->have[n] = true;
+  if (st == MRAG_OK) { e->have[n] = true; e->folded = false; }
   return st;
 }
 

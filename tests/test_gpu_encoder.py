@@ -87,6 +87,23 @@ def test_single_question_batches_match_oracle(arch, B, S, pool):
     np.testing.assert_allclose(big[:B], got, rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("arch,B,S,pool,layers", [("minilm-l6", 512, 32, "mean", 6), ("bge-base", 128, 96, "cls", 3)])
+def test_fused_layernorm_flow_matches_oracle(arch, B, S, pool, layers):
+    """Batches large enough for the 256 x 256 GEMMs take the fused-LayerNorm flow (csrc/encoder.hip LnArgs: gamma folded into the
+    consuming weights, per-token statistics from the producing GEMM's epilogue, residuals normalised on the fly): against the
+    oracle on a subsample of the rows, padded / ragged masks included."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec
+    spec = dict(oe.SPECS[arch], vocab_size=3000, max_position=128, layers=layers)
+    w = oe.seeded_weights(spec, 31)
+    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w)
+    ids, mask = _batch(spec, B, S, 17)
+    got = enc.forward(ids, mask, pool=pool)
+    sub = np.arange(0, B, B // 16)
+    want = oe.forward(spec, w, ids[sub], mask[sub], pool=pool)
+    np.testing.assert_allclose(got[sub], want, rtol=0, atol=TOL)
+    assert np.isfinite(got).all()
+
+
 @pytest.mark.parametrize("case", ["minilm2", "bge1"])
 def test_f6_hf_golden(golden_dir, case):
     """F6: the committed HF BertModel outputs (tests/golden/make_golden_encoder.py) -- MiniLM-L6 / bge-base layer

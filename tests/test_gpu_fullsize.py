@@ -121,7 +121,7 @@ def test_c3_encoder_full_shape_streamed_batches_match_oracle_subsample():
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-3)
         # batch composition does not change a row (padding rows are masked out)
         again = enc.forward(sid, smask, pool="cls")
-        np.testing.assert_allclose(again, got, rtol=0, atol=2e-4)
+        np.testing.assert_allclose(again, got, rtol=0, atol=5e-4)   # (a small batch takes the plain flow, the streamed ones the fused-LayerNorm flow)
 
 
 def test_c5_ivf_flat_per_gpu_share():
