@@ -376,7 +376,8 @@ constexpr int G2_A_BYTES = G2_T * GK * 2;            // 32 KiB: weight rows of a
 constexpr int G2_STAGE = 2 * G2_A_BYTES;             // 64 KiB
 constexpr int G2_PAD = 4096;                          // between the two stage buffers: either buffer + the pad holds the
 constexpr int G2_BUF1 = G2_STAGE + G2_PAD;            // epilogue's 128 x 528-byte output slab
-constexpr int G2_LDS = 2 * G2_STAGE + G2_PAD;         // 132 KiB
+constexpr int G2_VEC = 2048;                          // behind the stage buffers: bias / gamma of the tile's 256 columns (LNR epilogue)
+constexpr int G2_LDS = 2 * G2_STAGE + G2_PAD + G2_VEC;   // 134 KiB
 constexpr int G2_CPITCH = 528;                        // output row pitch in LDS: 256 columns x 2 B + 16 (bank shift per row)
 
 // LayerNorm folded into the GEMMs around it (LNF flags; forward_impl, "fused LayerNorm" flow):
@@ -553,9 +554,18 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
     // Every global load of the epilogue is issued HERE, back to back, and waited for once: written inside the
     // passes, hipcc puts an s_waitcnt vmcnt(0) behind each of them (8 bias + 32 residual loads = up to 40 serial
     // L2 round trips per tile), and in pass 1 that wait also sits out pass 0's stores (vmcnt counts in order).
-    float4 bv[8];
-    float4 xv[(LNF & 3) ? 8 : 1];               // LNA: s_n; LNR: gamma_n
-    e4 rr[8][(LNF & 2) ? 2 : 4];                // (LNR: the residual is loaded pass by pass -- the register budget)
+    constexpr bool VEC_LDS = (LNF & 2) != 0;     // LNR: bias and gamma of the tile's columns live in LDS (the register budget:
+                                                 // 128 accumulators + the 64 residual registers leave no room for two more vectors)
+    float* vec = (float*)(sm2 + 2 * G2_STAGE + G2_PAD);
+    if (VEC_LDS && tid < 128) {
+      const int n0 = tn * G2_T + (tid & 63) * 4;
+      float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 < N) t4 = *(const float4*)((tid < 64 ? bias : ln.r_gamma) + n0);
+      *(float4*)(vec + (tid >> 6) * 256 + (tid & 63) * 4) = t4;     // (visible after the barrier below)
+    }
+    float4 bv[VEC_LDS ? 1 : 8];
+    float4 xv[((LNF & 3) && !VEC_LDS) ? 8 : 1];  // LNA: s_n (LNR: gamma_n, in LDS)
+    e4 rr[8][4];
     float2 tst[(LNF & 3) ? 4 : 1];              // (mu, rstd) of this lane's four tokens
     float ps1[(LNF & 4) ? 4 : 1], ps2[(LNF & 4) ? 4 : 1];
     if (LNF & 3) {
@@ -570,13 +580,15 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
 #pragma unroll
     for (int mf = 0; mf < 8; ++mf) {
       const int n0 = n_b + mf * 16;
-      bv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 < N && !ENC_DBG(8)) bv[mf] = *(const float4*)(bias + n0);
-      if (LNF & 3) {
-        xv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 < N) xv[mf] = *(const float4*)(((LNF & 1) ? ln.s_vec : ln.r_gamma) + n0);
+      if (!VEC_LDS) {
+        bv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 < N && !ENC_DBG(8)) bv[mf] = *(const float4*)(bias + n0);
       }
-      if (EPI == EPI_RESID && !(LNF & 2) && !ENC_DBG(8)) {
+      if ((LNF & 3) && !VEC_LDS) {
+        xv[mf] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 < N) xv[mf] = *(const float4*)(ln.s_vec + n0);
+      }
+      if (EPI == EPI_RESID && !ENC_DBG(8)) {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           rr[mf][nf] = (e4){(elem)0.f, (elem)0.f, (elem)0.f, (elem)0.f};
@@ -584,27 +596,18 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
         }
       }
     }
+    if (VEC_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the bias / gamma vectors are in LDS before anyone passes the barrier
     __builtin_amdgcn_s_barrier();   // every wave has read its last fragments out of the buffer the slab reuses (lgkmcnt(0) in kstep)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      if (LNF & 2) {   // this pass's residual rows, all loads back to back
-#pragma unroll
-        for (int mf = 0; mf < 8; ++mf) {
-          const int n0 = n_b + mf * 16;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            rr[mf][h] = (e4){(elem)0.f, (elem)0.f, (elem)0.f, (elem)0.f};
-            if (n0 < N) rr[mf][h] = *(const e4*)(R + (size_t)(t_b + (pass * 2 + h) * 16) * N + n0);
-          }
-        }
-      }
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int nf = pass * 2 + h;
-          const float bq[4] = {bv[mf].x, bv[mf].y, bv[mf].z, bv[mf].w};
+          const float4 b4 = VEC_LDS ? *(const float4*)(vec + n_l + mf * 16) : bv[VEC_LDS ? 0 : mf];
+          const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
           float v[4];
           if (LNF & 1) {
             const float xq[4] = {xv[mf].x, xv[mf].y, xv[mf].z, xv[mf].w};
@@ -620,9 +623,10 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
           }
           if (EPI == EPI_RESID && !ENC_DBG(8)) {
             if (LNF & 2) {
-              const float xq[4] = {xv[mf].x, xv[mf].y, xv[mf].z, xv[mf].w};
+              const float4 g4 = *(const float4*)(vec + 256 + n_l + mf * 16);
+              const float xq[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += ((float)rr[mf][h][r] - tst[nf].x) * tst[nf].y * xq[r];
+              for (int r = 0; r < 4; ++r) v[r] += ((float)rr[mf][nf][r] - tst[nf].x) * tst[nf].y * xq[r];
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] += (float)rr[mf][nf][r];
