@@ -102,6 +102,9 @@ def test_fused_layernorm_flow_matches_oracle(arch, B, S, pool, layers):
     want = oe.forward(spec, w, ids[sub], mask[sub], pool=pool)
     np.testing.assert_allclose(got[sub], want, rtol=0, atol=TOL)
     assert np.isfinite(got).all()
+    if arch == "minilm-l6":                      # the same flow with bf16 weights / activations (coarser rounding: 8e-3, as the plain bf16 test)
+        enc16 = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w, dtype="bf16")
+        np.testing.assert_allclose(enc16.forward(ids, mask, pool=pool)[sub], want, rtol=0, atol=8e-3)
 
 
 @pytest.mark.parametrize("case", ["minilm2", "bge1"])
