@@ -1,7 +1,8 @@
 #!/bin/bash
-# In-kernel stamps of the IVF list-scan workgroup 0 (diagnostic build DIAG=16; timing shares only, see DESIGN).
+# In-kernel stamps of the FUSED-kernel IVF list scan (descriptor mode, forced with MRAG_IVF_SCORES_MB=0), workgroup 0
+# (diagnostic build DIAG=16; timing shares only, see DESIGN).  The score-segment scan has its own: ivf_stamps2.py.
 set -e
 cd "$(dirname "$0")/.."
 touch a-modular-rag-framework_amd/csrc/bf_index.hip
 make -C a-modular-rag-framework_amd/csrc DIAG=16 > gpurun_out/ivf_stamps_make.log 2>&1
-python tools/perf_ivf_encoder.py ivf 2>&1 | grep -v amdgpu.ids | grep -E "stamps|tail|IVF" | tail -${TAIL:-8}
+MRAG_IVF_SCORES_MB=0 python tools/perf_ivf_encoder.py ivf 2>&1 | grep -v amdgpu.ids | grep -E "stamps|tail|IVF" | tail -${TAIL:-8}
