@@ -12,7 +12,7 @@
 //                       so no gathered copy of the queries is ever written.  Scores go to HBM as fp32
 //                       segments S[query slot][row] (16-byte stores, 4 consecutive rows of one query per lane).
 //                       Same MFMA instruction and K order as the fused kernel: the scores are bit-identical to it.
-//   ivfs_select_kernel  one workgroup per query: its nprobe segments (a few thousand scores, L2-resident) are
+//   ivfs_select_*_kernel one workgroup per query: its nprobe segments (a few thousand scores, L2-resident) are
 //                       read once into LDS as orderable 32-bit keys, an MSB-first radix select finds the k-th
 //                       largest score, ties on it are resolved by original row (ascending), the k winners are
 //                       ranked by counting.  Order = (score desc, original row asc), as everywhere in this library.
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
 constexpr int SEL_THR = 256;
 constexpr int SEL_EPT = 32;                        // candidate scores a thread keeps in registers
 constexpr int SEL_CAP = SEL_THR * SEL_EPT;         // 8192 per query on the fast path; beyond it the serial (exact) path
-constexpr int SEL_CAND = 1024;                     // shortlisted entries (>= the k-th largest thread maximum)
+constexpr int SEL_CAND = 512;                      // shortlisted entries (>= the k-th largest thread maximum)
 constexpr int SEL_MAXP = 256;                      // probes per query
 constexpr int SEL_MAXK = 256;
 
@@ -242,7 +242,7 @@ struct SelParams {
 //   serial path (more than 8192 candidates, or a shortlist overflow = degenerate ties): k rounds of a workgroup-wide
 //              arg-max over the segments, rows looked up only for entries tied with the current score.
 template <bool DENSE>
-__global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
+__device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
   __shared__ const float* seg_ptr[SEL_MAXP];
   __shared__ int seg_cnt[SEL_MAXP];
   __shared__ int seg_pre[SEL_MAXP + 1];
@@ -439,6 +439,11 @@ __global__ __launch_bounds__(SEL_THR) void ivfs_select_kernel(SelParams p) {
   }
 }
 
+// (two entry points: the single-segment form fits 64 registers and runs 8 waves per SIMD -- 88 -> 71 us for 10 000 probe
+// selections --, the multi-segment form spills at that budget and is faster left alone)
+__global__ __launch_bounds__(SEL_THR) __attribute__((amdgpu_waves_per_eu(8, 8))) void ivfs_select_dense_kernel(SelParams p) { ivfs_select_body<true>(p); }
+__global__ __launch_bounds__(SEL_THR) void ivfs_select_lists_kernel(SelParams p) { ivfs_select_body<false>(p); }
+
 // ------------------------------------------------------------------ descriptors of the dense (probe selection) case
 __global__ void ivfs_dense_desc_kernel(int* __restrict__ desc, int n_qt, int n_chunks, int64_t nq, int n_rows, int rows_per_wg, int pitch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,7 +484,7 @@ int ivfs_select_lists(const float* S, const void* pinfo, int nprobe, int64_t nq,
   SelParams p{};
   p.S = S; p.pinfo = (const int4*)pinfo; p.row_ids = row_ids; p.nprobe = nprobe; p.k = k;
   p.id_base = id_base; p.out_scores = out_scores; p.out_ids = out_ids;
-  hipLaunchKernelGGL((ivfs_select_kernel<false>), dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
+  hipLaunchKernelGGL(ivfs_select_lists_kernel, dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
@@ -504,7 +509,7 @@ int ivfs_dense_topk(const uint16_t* corpus, int n_rows, const uint16_t* queries,
   SelParams p{};
   p.S = S; p.nprobe = 1; p.k = k; p.dense_rows = n_rows; p.dense_pitch = pitch; p.out_scores = out_scores; p.out_ids = out_ids;
   p.count_out = count_out; p.row_weight = row_weight;
-  hipLaunchKernelGGL((ivfs_select_kernel<true>), dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
+  hipLaunchKernelGGL(ivfs_select_dense_kernel, dim3((unsigned)nq), dim3(SEL_THR), 0, stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
