@@ -129,7 +129,7 @@ def ivf_leg(device, k):
     nbytes = t["scanned_rows"] * d * 2.0
     ach = nbytes / (scan_ms * 1e-3) / 1e9
     ix.close(); bf.close()
-    return {"bound": "hbm", "kernel": "ivfs_scan_kernel + ivfs_select_kernel (IVF list scan: fp32 score segments, then the k best per query)",
+    return {"bound": "hbm", "kernel": "ivfs_scan_kernel + ivfs_select_lists_kernel (IVF list scan: fp32 score segments, then the k best per query)",
             "workload": f"C5 per-GPU share: {n} x {d} fp16, nlist {nlist}, nprobe {nprobe}, {nq} queries, k={k}, clustered rows",
             "kernel_ms": scan_ms, "search_ms": tot_ms, "queries_per_s": nq / (tot_ms * 1e-3),
             "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
