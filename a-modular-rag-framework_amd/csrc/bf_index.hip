@@ -182,6 +182,15 @@ __device__ __forceinline__ void lds_store_u32(void* p, uint32_t x) {
 #ifndef MRAG_S_POLICY
 #define MRAG_S_POLICY " nt"
 #endif
+// K walk of the batch kernel.  1 / 2 = corpus tiles with an odd global index / odd index inside the split walk their K
+// steps last-to-first, so that the query K slices a workgroup has just used are the ones it asks for next (LRU-friendly:
+// the VERDICT r2 #1a experiment).  Measured round 3, same box, interleaved (tools/ab.sh): 10 000 x 1 M x 768
+// 13.83 / 13.88 / 13.90 ms forward vs 14.05 / 14.01 / 14.02 (by global parity) and 14.02 / 14.06 / 14.02 (by split
+// parity): 1.2 % SLOWER; 1 000 x 1 M 1.593-1.600 vs 1.593-1.613; C2 unchanged.  It also makes a row's fp32 accumulation
+// order depend on its tile parity (sharded != unsharded in the last bit).  Not taken: 0.
+#ifndef MRAG_ZZ
+#define MRAG_ZZ 0
+#endif
 
 // Diagnostics (ablations, s_memtime stamps) exist only in a -DMRAG_DIAG=<flags> build (make DIAG=<flags>):
 // the flags are COMPILE-TIME constants, so an ablated build carries no extra branches or registers
@@ -579,11 +588,18 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   const int n_tiles = tile_hi - tile_lo;
   const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(CPW * w) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
   int pf_kk = 0, pf_left = n_tiles * ksteps;
+  // K walk direction (MRAG_ZZ, see the top of the file): 0 = every corpus tile first-to-last (shipped)
+  int pf_tile = (MRAG_ZZ == 2) ? 0 : tile_lo;
+  auto pf_koff = [&]() -> int {
+    if (DESC || MRAG_ZZ == 0) return pf_kk * (BK * 2);
+    return ((pf_tile & 1) ? (ksteps - 1 - pf_kk) : pf_kk) * (BK * 2);
+  };
   int buf = 0;
   if (pf_left > 0) {
-    stage(a_tile, q_ptr, 0);
+    const int ko = pf_koff();
+    stage(a_tile + ko, q_ptr + ko, 0);
     --pf_left;
-    if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+    if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; ++pf_tile; }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -601,12 +617,13 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     // feeds the MFMA pipe again after 2 DMA issues instead of 8 (all at the top: 13.38 ms; 4 + 4: 13.21; 2 + 6: 13.22
     // vs 13.38 in a second pairing).
     const bool do_stage = pf_left > 0 && !MRAG_DBG(4);   // diag 4: ablate the loads
-    const char* st_a = a_tile + pf_kk * (BK * 2);
-    const char* st_b = q_ptr + pf_kk * (BK * 2);
+    const int st_ko = pf_koff();
+    const char* st_a = a_tile + st_ko;
+    const char* st_b = q_ptr + st_ko;
     const int st_buf = buf ^ 1;
     if (do_stage) {
       --pf_left;
-      if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; }
+      if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; ++pf_tile; }
       stage_part(st_a, st_b, st_buf, 0);
       if (!PENDING || MRAG_DBG(8)) { stage_part(st_a, st_b, st_buf, 1); stage_part(st_a, st_b, st_buf, 2); stage_part(st_a, st_b, st_buf, 3); }
     }

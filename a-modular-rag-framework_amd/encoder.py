@@ -100,9 +100,14 @@ class HashingTokenizer:
 
 
 class WordPieceTokenizer:
-    def __init__(self, vocab_file: str):
+    """BERT WordPiece over a ``vocab.txt`` (``tokenizers.BertWordPieceTokenizer``: basic tokenisation -- clean-up,
+    lower-casing + accent stripping, punctuation and CJK splitting -- then greedy longest-match pieces); ids equal
+    ``transformers.BertTokenizer``'s on fixture F9.  Over-long sequences are cut the sentence-transformers way: the
+    first ``max_length - 1`` ids + the final [SEP]."""
+
+    def __init__(self, vocab_file: str, lowercase: bool = True):
         from tokenizers import BertWordPieceTokenizer
-        self._tok = BertWordPieceTokenizer(vocab_file, lowercase=True)
+        self._tok = BertWordPieceTokenizer(vocab_file, lowercase=lowercase)
 
     def encode(self, text: str, max_length: int) -> List[int]:
         return self._truncate(self._tok.encode(text or "").ids, max_length)
@@ -112,7 +117,66 @@ class WordPieceTokenizer:
         return ids if len(ids) <= max_length else ids[: max_length - 1] + [ids[-1]]
 
 
+def read_pretrained_dir(path: str, max_length: Optional[int] = None):
+    """Parse a local HF / sentence-transformers model directory (no GPU needed):
+
+    * ``config.json`` -> :class:`EncoderSpec`;
+    * ``model.safetensors`` (``safetensors``) or ``pytorch_model.bin`` (``torch.load(weights_only=True)``) -> fp32 arrays
+      under HF's ``BertModel`` names (a ``bert.`` prefix is dropped by the constructor);
+    * ``vocab.txt`` -> :class:`WordPieceTokenizer` (``tokenizer_config.json:do_lower_case``, default true);
+    * ``1_Pooling/config.json`` -> "cls" / "mean"; ``modules.json`` -> whether a Normalize module closes the pipeline
+      (no ``modules.json``: a plain HF directory, vectors are normalised as the cosine index needs);
+    * ``sentence_bert_config.json:max_seq_length`` caps the sequence length (sentence-transformers truncates there),
+      then ``max_position_embeddings``; an explicit ``max_length`` wins over both.
+
+    -> (spec, weights, tokenizer or None, {"normalize": bool, "max_seq_length": int})"""
+    p = Path(path)
+    cfg = json.loads((p / "config.json").read_text())
+    pool = "mean"
+    st_cfg = p / "1_Pooling" / "config.json"
+    if st_cfg.exists():
+        pc = json.loads(st_cfg.read_text())
+        if pc.get("pooling_mode_cls_token"):
+            pool = "cls"
+        elif not pc.get("pooling_mode_mean_tokens", True):
+            raise ValueError(f"{st_cfg}: only CLS and mean pooling are implemented")
+    max_seq = int(cfg["max_position_embeddings"])
+    sb = p / "sentence_bert_config.json"
+    if sb.exists():
+        ms = json.loads(sb.read_text()).get("max_seq_length")
+        if ms:
+            max_seq = min(max_seq, int(ms))
+    normalize = True
+    mods = p / "modules.json"
+    if mods.exists():
+        normalize = any(str(m.get("type", "")).endswith("Normalize") for m in json.loads(mods.read_text()))
+    spec = EncoderSpec(vocab_size=cfg["vocab_size"], hidden=cfg["hidden_size"], layers=cfg["num_hidden_layers"],
+                       heads=cfg["num_attention_heads"], intermediate=cfg["intermediate_size"],
+                       max_position=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
+                       layer_norm_eps=cfg.get("layer_norm_eps", 1e-12), pool=pool,
+                       max_length=min(int(max_length), int(cfg["max_position_embeddings"])) if max_length else min(512, max_seq))
+    if cfg.get("hidden_act", "gelu") not in ("gelu",):
+        raise ValueError(f"hidden_act {cfg.get('hidden_act')!r}: the HIP encoder implements erf-GELU only")
+    if (p / "model.safetensors").exists():
+        from safetensors.numpy import load_file
+        weights = {k: np.asarray(v, dtype=np.float32) for k, v in load_file(str(p / "model.safetensors")).items()}
+    else:
+        import torch
+        sd = torch.load(str(p / "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        weights = {k: v.float().numpy() for k, v in sd.items()}
+    tok = None
+    if (p / "vocab.txt").exists():
+        lower = True
+        tc = p / "tokenizer_config.json"
+        if tc.exists():
+            lower = bool(json.loads(tc.read_text()).get("do_lower_case", True))
+        tok = WordPieceTokenizer(str(p / "vocab.txt"), lowercase=lower)
+    return spec, weights, tok, {"normalize": normalize, "max_seq_length": max_seq}
+
+
 class HipSentenceEncoder:
+    normalize_default = True      # from_pretrained_dir: whether the directory's pipeline ends in a Normalize module
+
     def __init__(self, spec: EncoderSpec, weights: Dict[str, np.ndarray], tokenizer=None, device: int = 0,
                  dtype: str = "f16", max_length: Optional[int] = None):
         self._lib = N.load()
@@ -143,27 +207,12 @@ class HipSentenceEncoder:
 
     @classmethod
     def from_pretrained_dir(cls, path: str, **kw) -> "HipSentenceEncoder":
-        p = Path(path)
-        cfg = json.loads((p / "config.json").read_text())
-        pool = "mean"
-        st_cfg = p / "1_Pooling" / "config.json"
-        if st_cfg.exists():
-            pc = json.loads(st_cfg.read_text())
-            pool = "cls" if pc.get("pooling_mode_cls_token") else "mean"
-        spec = EncoderSpec(vocab_size=cfg["vocab_size"], hidden=cfg["hidden_size"], layers=cfg["num_hidden_layers"],
-                           heads=cfg["num_attention_heads"], intermediate=cfg["intermediate_size"],
-                           max_position=cfg["max_position_embeddings"], type_vocab_size=cfg.get("type_vocab_size", 2),
-                           layer_norm_eps=cfg.get("layer_norm_eps", 1e-12), pool=pool,
-                           max_length=kw.get("max_length") or min(512, cfg["max_position_embeddings"]))
-        if (p / "model.safetensors").exists():
-            from safetensors.numpy import load_file
-            weights = load_file(str(p / "model.safetensors"))
-        else:
-            import torch
-            sd = torch.load(str(p / "pytorch_model.bin"), map_location="cpu", weights_only=True)
-            weights = {k: v.float().numpy() for k, v in sd.items()}
-        tok = WordPieceTokenizer(str(p / "vocab.txt")) if (p / "vocab.txt").exists() else None
-        return cls(spec, weights, tokenizer=tok, **kw)
+        """A local HF / sentence-transformers directory -> encoder (the real-weights route of the Embedder slot;
+        pinned by fixture F9, tests/golden/make_golden_hfdir.py)."""
+        spec, weights, tok, info = read_pretrained_dir(path, max_length=kw.pop("max_length", None))
+        enc = cls(spec, weights, tokenizer=tok, **kw)
+        enc.normalize_default = info["normalize"]
+        return enc
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -32,7 +32,7 @@ from . import corpus as _corpus
 class HipEmbeddingProvider:
     def __init__(self, arch: str = "minilm-l6", model_path: Optional[str] = None,
                  embed_model: Optional[str] = None, device: int = 0, batch_size: int = 256,
-                 max_length: Optional[int] = None, seed: int = 0, normalize: bool = True, **extra):
+                 max_length: Optional[int] = None, seed: int = 0, normalize: Optional[bool] = None, **extra):
         self.kwargs: Dict[str, Any] = dict(arch=arch, model_path=model_path, device=device, batch_size=batch_size,
                                            max_length=max_length, seed=seed, normalize=normalize, **extra)
         self.kwargs["embed_model"] = embed_model or (model_path.rstrip("/").split("/")[-1] if model_path else arch)
@@ -75,8 +75,10 @@ class HipEmbeddingProvider:
         tokenizer always emits [CLS] [SEP])."""
         if not texts:
             return np.zeros((0, self.dim), dtype=np.float32)
-        return self.encoder.encode([t if isinstance(t, str) else str(t) for t in texts],
-                                   batch_size=int(self.kwargs["batch_size"]), normalize=bool(self.kwargs["normalize"]))
+        enc = self.encoder
+        norm = self.kwargs["normalize"]      # None: what the model directory's pipeline does (Normalize module), else True
+        return enc.encode([t if isinstance(t, str) else str(t) for t in texts], batch_size=int(self.kwargs["batch_size"]),
+                          normalize=bool(enc.normalize_default if norm is None else norm))
 
     def embed(self, texts: Optional[List[str]] = None, *, model: Optional[str] = None,
               require: Optional[Dict[str, Any]] = None, **kw) -> Dict[str, Any]:

@@ -42,8 +42,55 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
+class _Phases:
+    """Per-phase milliseconds of one exchange.  CUDA inputs: events on the current stream, read after the call's
+    final stream sync (no extra sync); host inputs: ``time.perf_counter``."""
+
+    def __init__(self, cuda: bool, device=None):
+        self.cuda, self.device, self.marks = cuda, device, []
+
+    def mark(self, name: str):
+        if self.cuda:
+            import torch
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            self.marks.append((name, e))
+        else:
+            import time
+            self.marks.append((name, time.perf_counter()))
+
+    def result(self) -> dict:
+        out = {}
+        for (_, a), (name, b) in zip(self.marks, self.marks[1:]):
+            ms = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+            out[name] = out.get(name, 0.0) + float(ms)
+        return out
+
+
+def _bases_tensor(bufs: dict, id_bases, world: int, device):
+    """[world,1,1] int64 tensor of the ranks' first global rows, cached per VALUE of ``id_bases`` (another
+    ``n_total`` or shard layout with the same world / q / k must never reuse the previous bases)."""
+    import torch
+    if id_bases is None:
+        raise ValueError("gather_and_merge needs id_bases (first global row of every rank) for N > 1")
+    key = tuple(int(b) for b in id_bases)
+    if len(key) != world:
+        raise ValueError(f"id_bases has {len(key)} entries for a world of {world}")
+    if bufs.get("bases_key") != key:
+        bufs["bases_key"] = key
+        bufs["bases"] = torch.as_tensor(list(key), dtype=torch.int64, device=device).view(world, 1, 1)
+    return key, bufs["bases"]
+
+
+def _raise_if_bad(bad_host) -> None:
+    if int(bad_host) != 0:
+        raise ValueError("gather_and_merge: a local id lies outside [id_base, id_base + 2^32 - 1) -- the packed exchange "
+                         "carries shard-local rows in 32 bits (is the index's id_base set to the shard's first row?)")
+
+
 def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, bufs: Optional[dict] = None,
-                     merge: str = "auto", force_collective: bool = False, id_bases=None) -> Tuple[np.ndarray, np.ndarray]:
+                     merge: str = "auto", force_collective: bool = False, id_bases=None,
+                     phases: Optional[dict] = None) -> Tuple[np.ndarray, np.ndarray]:
     """All-gather the per-shard partial top-k and merge.  ``merge``: "host" (mrag_topk_merge),
     "device" (mrag_topk_merge_device, CUDA tensors only) or "auto" (device when it applies).
 
@@ -52,7 +99,9 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
     (scores [Q,k] float32, ids [Q,k] int64) as numpy arrays.  ``bufs`` (a dict the caller
     keeps) caches the gather / pinned staging buffers across calls; with CUDA inputs the returned
     arrays are views of pinned buffers that stay valid until the call after the next one.
-    ``id_bases``: first global row of every rank's shard (needed when more than one rank takes part)."""
+    ``id_bases``: first global row of every rank's shard (needed when more than one rank takes part);
+    ids must lie in [id_base, id_base + 2^32 - 1) of their rank -- anything else raises, it never wraps.
+    ``phases`` (a dict) receives pack_ms / gather_ms / merge_ms / d2h_ms of this call."""
     import torch
     import torch.distributed as dist
 
@@ -64,10 +113,14 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
             return (local_scores.detach().numpy().astype(np.float32, copy=False),
                     local_ids.detach().numpy().astype(np.int64, copy=False))
         # one pinned D2H per array + one stream sync (pageable .cpu() costs two blocking staged copies)
+        ph = _Phases(True, local_scores.device) if phases is not None else None
+        if ph: ph.mark("start")
         hs, hi = _host_pair(bufs, q, k)
         hs.copy_(local_scores, non_blocking=True)
         hi.copy_(local_ids, non_blocking=True)
+        if ph: ph.mark("d2h_ms")
         torch.cuda.current_stream(local_scores.device).synchronize()
+        if ph: phases.update(ph.result())
         return hs.numpy(), hi.numpy()
     key = (world, q, k, str(local_scores.device))
     if bufs.get("key") != key:
@@ -75,25 +128,41 @@ def gather_and_merge(local_scores, local_ids, group=None, nthreads: int = 0, buf
         bufs["key"] = key
         bufs["gw"] = torch.empty((world, q, k), dtype=torch.int64, device=local_scores.device)
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    bases = bufs.get("bases")
-    if bases is None or bases.shape[0] != world:
-        if id_bases is None:
-            raise ValueError("gather_and_merge needs id_bases (first global row of every rank) for N > 1")
-        bases = bufs["bases"] = torch.as_tensor(list(id_bases), dtype=torch.int64, device=local_scores.device).view(world, 1, 1)
+    base_list, bases = _bases_tensor(bufs, id_bases, world, local_scores.device)
     gw = bufs["gw"]
-    # ONE collective: (score bits << 32) | shard-local row (0xFFFFFFFF = empty slot); output = the inputs
-    # concatenated along dim 0 (the layout both nccl and gloo accept)
-    dist.all_gather_into_tensor(gw.view(world * q, k), pack_partial(local_scores, local_ids, int(bases[rank])), group=group)
+    ph = _Phases(local_scores.is_cuda, local_scores.device) if phases is not None else None
+    if ph: ph.mark("start")
+    # ONE collective: (score bits << 32) | shard-local row (0xFFFFFFFF = empty slot); this rank's base comes from
+    # the HOST list (reading bases[rank] back from the device would be a blocking sync inside the exchange);
+    # output = the inputs concatenated along dim 0 (the layout both nccl and gloo accept)
+    words, bad = pack_partial(local_scores, local_ids, base_list[rank], return_bad=True)
+    if ph: ph.mark("pack_ms")
+    dist.all_gather_into_tensor(gw.view(world * q, k), words, group=group)
+    if ph: ph.mark("gather_ms")
+    if not bad.is_cuda:
+        _raise_if_bad(bad.item())
+        bad = None
     gs, gi = unpack_partial(gw, bases)
-    return merge_gathered(gs, gi, bufs, merge=merge, nthreads=nthreads)
+    out = merge_gathered(gs, gi, bufs, merge=merge, nthreads=nthreads, bad=bad, phases=ph)
+    if ph: phases.update(ph.result())
+    return out
 
 
-def pack_partial(scores, ids, id_base: int):
+def pack_partial(scores, ids, id_base: int, return_bad: bool = False):
     """[Q,k] fp32 scores + int64 GLOBAL ids (-1 = empty) -> int64 words: score bits in the high half, the
-    shard-local row (id - id_base, 32 bits) in the low half."""
+    shard-local row (id - id_base, 32 bits) in the low half.  ``return_bad``: also a 1-element int64 tensor,
+    non-zero when some non-empty id is outside [id_base, id_base + 0xFFFFFFFF).  The caller raises AFTER the
+    collective (a rank that raised before it would leave the others waiting in it); on CUDA the flag rides along
+    with the result copy and is checked after the call's one sync instead of forcing a sync inside the exchange."""
     import torch
-    local = torch.where(ids >= 0, ids - id_base, torch.full_like(ids, 0xFFFFFFFF))
-    return (scores.contiguous().view(torch.int32).to(torch.int64) << 32) | (local & 0xFFFFFFFF)
+    local = ids - id_base
+    empty = ids < 0
+    words = (scores.contiguous().view(torch.int32).to(torch.int64) << 32) | \
+        (torch.where(empty, torch.full_like(ids, 0xFFFFFFFF), local) & 0xFFFFFFFF)
+    if not return_bad:
+        return words
+    bad = (((local < 0) | (local >= 0xFFFFFFFF)) & ~empty).any().to(torch.int64).view(1)
+    return words, bad
 
 
 def unpack_partial(words, bases):
@@ -105,13 +174,20 @@ def unpack_partial(words, bases):
     return scores, ids
 
 
-def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0, bad=None, phases=None
+                   ) -> Tuple[np.ndarray, np.ndarray]:
     """Merge gathered partial top-k ``gs`` / ``gi`` [world, Q, k] (torch tensors, CUDA or CPU) into host
     arrays [Q, k].  CUDA input: merged on the device, then ONE pinned D2H of the result ("device" /
-    "auto"), or pinned D2H of everything + the host merge ("host")."""
+    "auto"), or pinned D2H of everything + the host merge ("host").  ``bad``: the pack's range flag (a CUDA
+    tensor rides along with the result copy and is checked after the one stream sync)."""
     import torch
     world, q, k = gs.shape
     if gs.is_cuda:
+        hbad = None
+        if bad is not None:
+            if "hbad" not in bufs:
+                bufs["hbad"] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+            hbad = bufs["hbad"]
         on_device = merge == "device" or (merge == "auto" and world <= 64 and world * k <= 2048)
         if on_device:
             if bufs.get("mkey") != (q, k):
@@ -119,10 +195,16 @@ def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0) -
                 bufs["ms"] = torch.empty((q, k), dtype=torch.float32, device=gs.device)
                 bufs["mi"] = torch.empty((q, k), dtype=torch.int64, device=gs.device)
             topk_merge_device(gs, gi, bufs["ms"], bufs["mi"])
+            if phases: phases.mark("merge_ms")
             hs, hi = _host_pair(bufs, q, k)
             hs.copy_(bufs["ms"], non_blocking=True)
             hi.copy_(bufs["mi"], non_blocking=True)
+            if hbad is not None:
+                hbad.copy_(bad, non_blocking=True)
+            if phases: phases.mark("d2h_ms")
             torch.cuda.current_stream(gs.device).synchronize()
+            if hbad is not None:
+                _raise_if_bad(hbad.item())
             return hs.numpy(), hi.numpy()
         if "hs" not in bufs:
             bufs["hs"] = torch.empty((world, q, k), dtype=torch.float32, pin_memory=True)
@@ -130,11 +212,18 @@ def merge_gathered(gs, gi, bufs: dict, merge: str = "auto", nthreads: int = 0) -
         hs, hi = bufs["hs"], bufs["hi"]
         hs.copy_(gs, non_blocking=True)
         hi.copy_(gi, non_blocking=True)
+        if hbad is not None:
+            hbad.copy_(bad, non_blocking=True)
+        if phases: phases.mark("d2h_ms")
         torch.cuda.current_stream(gs.device).synchronize()
+        if hbad is not None:
+            _raise_if_bad(hbad.item())
         return topk_merge(hs.numpy(), hi.numpy(), nthreads)
     if merge == "device":
         raise ValueError("merge='device' needs CUDA tensors")
-    return topk_merge(gs.numpy(), gi.numpy(), nthreads)
+    out = topk_merge(gs.numpy(), gi.numpy(), nthreads)
+    if phases: phases.mark("merge_ms")
+    return out
 
 
 class ShardedDenseIndex:
@@ -150,6 +239,7 @@ class ShardedDenseIndex:
         self.dim, self.n_total, self.rank, self.world, self.group = dim, n_total, rank, world, group
         self.lo, self.hi = shard_bounds(n_total, world, rank)
         self._bufs: dict = {}
+        self.last_phases: dict = {}
         self.index = None
         if local_search is None:
             from .index import DenseIndex
@@ -166,22 +256,111 @@ class ShardedDenseIndex:
             raise ValueError("more rows than this shard owns")
 
     def search(self, queries, k: int, nthreads: int = 0, merge: str = "auto", force_collective: bool = False,
-               **kw) -> Tuple[np.ndarray, np.ndarray]:
+               pipeline: bool = False, **kw) -> Tuple[np.ndarray, np.ndarray]:
+        """Local search over this rank's rows, then the exchange + merge; every rank returns the full result.
+        ``pipeline=True`` cuts the batch in two halves: the all-gather of half A is in flight (``async_op``, on the
+        process group's own stream) while the local search of half B runs -- same result, bit for bit (every query's
+        answer depends on its own rows of the batch only).  ``self.last_phases`` holds the call's per-phase
+        milliseconds: local_ms, pack_ms, gather_ms (in pipeline mode: the part of the collective the local search
+        did NOT cover), merge_ms, d2h_ms."""
         import torch
-        if self.index is not None and torch.is_tensor(queries) and queries.is_cuda and "out" not in kw:
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        is_cuda = torch.is_tensor(queries) and queries.is_cuda
+        id_bases = [shard_bounds(self.n_total, self.world, r)[0] for r in range(self.world)]
+        nq = int(queries.shape[0])
+        if self.index is not None and is_cuda and "out" not in kw:
             # reuse the device result tensors across calls (they are consumed by the exchange below)
-            key = (int(queries.shape[0]), int(k), queries.device)
+            key = (nq, int(k), queries.device)
             if self._bufs.get("okey") != key:
                 self._bufs["okey"] = key
                 self._bufs["osc"] = torch.empty((key[0], key[1]), dtype=torch.float32, device=queries.device)
                 self._bufs["oid"] = torch.empty((key[0], key[1]), dtype=torch.int64, device=queries.device)
             kw = dict(kw, out=(self._bufs["osc"], self._bufs["oid"]))
+        if pipeline and (world > 1 or force_collective) and nq >= 2:
+            return self._search_two_halves(queries, k, nthreads, merge, id_bases, world, is_cuda, kw)
+        ph = _Phases(is_cuda, queries.device if is_cuda else None)
+        ph.mark("start")
         sc, ids = self._local_search(queries, k, **kw)
+        ph.mark("local_ms")
         if not torch.is_tensor(sc):
             sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
-        return gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
-                                force_collective=force_collective,
-                                id_bases=[shard_bounds(self.n_total, self.world, r)[0] for r in range(self.world)])
+        rest: dict = {}
+        out = gather_and_merge(sc, ids, group=self.group, nthreads=nthreads, bufs=self._bufs, merge=merge,
+                               force_collective=force_collective, id_bases=id_bases, phases=rest)
+        self.last_phases = dict(ph.result(), **rest)
+        return out
+
+    def _search_two_halves(self, queries, k, nthreads, merge, id_bases, world, is_cuda, kw):
+        import torch
+        import torch.distributed as dist
+        nq = int(queries.shape[0])
+        h = nq // 2
+        if h > 256:
+            h = (h + 255) // 256 * 256          # cut on a query-tile boundary of the batch kernel
+        cuts = [(0, h), (h, nq)]
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        out_pair = kw.pop("out", None)
+        ph = _Phases(is_cuda, queries.device if is_cuda else None)
+        ph.mark("start")
+        inflight = []
+        for a, b in cuts:
+            kwh = dict(kw, out=(out_pair[0][a:b], out_pair[1][a:b])) if out_pair is not None else kw
+            sc, ids = self._local_search(queries[a:b], k, **kwh)
+            ph.mark("local_ms")
+            if not torch.is_tensor(sc):
+                sc, ids = torch.from_numpy(np.ascontiguousarray(sc)), torch.from_numpy(np.ascontiguousarray(ids))
+            bkey = ("gw2", a, b, world, int(k), str(sc.device))
+            if bkey not in self._bufs:
+                self._bufs[bkey] = torch.empty((world, b - a, k), dtype=torch.int64, device=sc.device)
+            gw = self._bufs[bkey]
+            base_list, bases = _bases_tensor(self._bufs, id_bases, world, sc.device)
+            words, bad = pack_partial(sc, ids, base_list[rank], return_bad=True)
+            ph.mark("pack_ms")
+            work = dist.all_gather_into_tensor(gw.view(world * (b - a), k), words, group=self.group, async_op=True)
+            inflight.append((work, words, bad, gw, bases))      # (words stays referenced until the collective is done)
+        on_device = is_cuda and (merge == "device" or (merge == "auto" and world <= 64 and world * k <= 2048))
+        parts = []
+        if on_device:
+            mkey = ("m2", nq, int(k))
+            if mkey not in self._bufs:
+                self._bufs[mkey] = (torch.empty((nq, k), dtype=torch.float32, device=queries.device),
+                                    torch.empty((nq, k), dtype=torch.int64, device=queries.device))
+            ms, mi = self._bufs[mkey]
+        for (a, b), (work, words, bad, gw, bases) in zip(cuts, inflight):
+            work.wait()                          # nccl: the current stream waits for the collective; gloo: the host does
+            ph.mark("gather_ms")
+            if not is_cuda and (a, b) == cuts[-1]:
+                _raise_if_bad((inflight[0][2] | inflight[1][2]).item())
+            gs, gi = unpack_partial(gw, bases)
+            if on_device:
+                topk_merge_device(gs, gi, ms[a:b], mi[a:b])
+            elif is_cuda:
+                parts.append((gs.cpu().numpy(), gi.cpu().numpy()))
+            else:
+                parts.append(topk_merge(gs.numpy(), gi.numpy(), nthreads))
+            ph.mark("merge_ms")
+        if is_cuda:
+            if "hbad" not in self._bufs:
+                self._bufs["hbad"] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+            hbad = self._bufs["hbad"]
+            hbad.copy_(inflight[0][2] | inflight[1][2], non_blocking=True)
+            if on_device:
+                hs, hi = _host_pair(self._bufs, nq, k)
+                hs.copy_(ms, non_blocking=True)
+                hi.copy_(mi, non_blocking=True)
+            ph.mark("d2h_ms")
+            torch.cuda.current_stream(queries.device).synchronize()
+            _raise_if_bad(hbad.item())
+            if on_device:
+                out = hs.numpy(), hi.numpy()
+            else:
+                parts = [topk_merge(s_, i_, nthreads) for s_, i_ in parts]
+                out = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
+        else:
+            out = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
+        self.last_phases = ph.result()
+        return out
 
 
 class ShardedIVFIndex:

@@ -96,6 +96,32 @@ for _ in range(2):                     # second call reuses the gather buffers
 rv, ri = ds.brute_force_topk(q16, c16, k)
 assert (i == ri).all(), "sharded ids differ from unsharded"
 assert np.array_equal(v, rv.astype(np.float32))
+assert set(sh.last_phases) >= {"local_ms", "pack_ms", "gather_ms", "merge_ms"}, sh.last_phases
+# two-half pipeline (all-gather of half A in flight under the local search of half B): exactly the one-shot result
+vp, ip = sh.search(q16, k, pipeline=True)
+assert np.array_equal(ip, i) and np.array_equal(vp, v)
+assert set(sh.last_phases) >= {"local_ms", "pack_ms", "gather_ms", "merge_ms"}, sh.last_phases
+vp1, ip1 = sh.search(q16[:1], k, pipeline=True)      # a single query cannot be cut: falls back to one shot
+assert np.array_equal(ip1, i[:1])
+# ADVICE r2: one caller-kept `bufs` reused with ANOTHER n_total (same world / q / k) must not reuse stale bases
+from mrag_amd.sharded import gather_and_merge
+bufs = {}
+for n2 in (n, 2000):
+    lo2, hi2 = shard_bounds(n2, world, rank)
+    v2, i2 = ds.brute_force_topk(q16, c16[lo2:hi2], k)
+    i2 = np.where(i2 >= 0, i2 + lo2, i2)
+    gv, gi = gather_and_merge(torch.from_numpy(v2.astype(np.float32)), torch.from_numpy(i2), bufs=bufs,
+                              id_bases=[shard_bounds(n2, world, r)[0] for r in range(world)])
+    rv2, ri2 = ds.brute_force_topk(q16, c16[:n2], k)
+    assert (gi == ri2).all(), f"stale id bases after n_total changed to {n2}"
+# ... and ids that do not fit the 32-bit shard-local slot raise on every rank, they never wrap
+bad_ids = torch.from_numpy(i2).clone(); bad_ids[0, 0] = lo2 - 1 if lo2 > 0 else lo2 + 2**32
+try:
+    gather_and_merge(torch.from_numpy(v2.astype(np.float32)), bad_ids, bufs=bufs,
+                     id_bases=[shard_bounds(n2, world, r)[0] for r in range(world)])
+    raise SystemExit("out-of-range id was packed silently")
+except ValueError as e:
+    assert "outside" in str(e)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -79,3 +79,49 @@ def test_oracle_and_weight_generators_match_f6_fixture(golden_dir, case):
     ids, mask, pool = z[f"{case}.ids"], z[f"{case}.mask"], str(z[f"{case}.pool"])
     np.testing.assert_allclose(oe.forward(spec, w, ids, mask, pool=pool), z[f"{case}.emb"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(oe.forward(spec, w, ids, mask, pool=pool, normalize=False), z[f"{case}.raw"], rtol=0, atol=2e-4)
+
+
+# ---- F9: the real-weights route (a builder-generated HF / sentence-transformers directory) ----------
+def _f9(golden_dir):
+    import json
+    return json.loads((golden_dir / "f9_hf.json").read_text()), golden_dir / "f9_hf_dir"
+
+
+def test_f9_wordpiece_ids_equal_hf_tokenizer(golden_dir):
+    """``WordPieceTokenizer`` ids == ``transformers.BertTokenizer`` ids (stored by make_golden_hfdir.py), bit for bit:
+    accents, CJK, control characters, > 100-character words, literal specials, truncation at max_seq_length."""
+    from mrag_amd.encoder import WordPieceTokenizer
+    g, d = _f9(golden_dir)
+    tok = WordPieceTokenizer(str(d / "vocab.txt"))
+    assert len(g["texts"]) >= 50 and any(len(x) > g["max_seq_length"] for x in g["ids_untruncated"])
+    for text, ids, full in zip(g["texts"], g["ids"], g["ids_untruncated"]):
+        assert tok.encode(text, g["max_seq_length"]) == ids, text
+        assert tok.encode(text, 10 ** 6) == full, text
+
+
+def test_f9_directory_is_read_as_sentence_transformers_would(golden_dir):
+    """config.json / 1_Pooling / modules.json (Normalize) / sentence_bert_config.json:max_seq_length / safetensors."""
+    from mrag_amd.encoder import read_pretrained_dir
+    g, d = _f9(golden_dir)
+    spec, w, tok, info = read_pretrained_dir(str(d))
+    assert (spec.hidden, spec.layers, spec.heads, spec.intermediate, spec.max_position) == (64, 2, 2, 256, 96)
+    assert spec.vocab_size == g["vocab_size"] and spec.pool == "mean"
+    assert spec.max_length == g["max_seq_length"] == info["max_seq_length"] and info["normalize"] is True
+    assert tok is not None and w["embeddings.word_embeddings.weight"].shape == (g["vocab_size"], 64)
+    assert read_pretrained_dir(str(d), max_length=16)[0].max_length == 16          # an explicit cap wins
+    assert read_pretrained_dir(str(d), max_length=4096)[0].max_length == 96        # ... up to the position table
+
+
+def test_f9_oracle_matches_hf_from_pretrained(golden_dir):
+    """The oracle on the directory's weights and the stored HF token ids reproduces HF's
+    ``BertModel.from_pretrained(dir)`` + pooling + normalise (both poolings)."""
+    from mrag_amd.encoder import read_pretrained_dir
+    g, d = _f9(golden_dir)
+    spec, w, _, _ = read_pretrained_dir(str(d))
+    S = max(len(x) for x in g["ids"])
+    ids = np.zeros((len(g["ids"]), S), dtype=np.int64); mask = np.zeros_like(ids)
+    for i, x in enumerate(g["ids"]):
+        ids[i, :len(x)] = x; mask[i, :len(x)] = 1
+    sp = dict(spec.as_dict())
+    for pool, key in (("mean", "mean_normalized"), ("cls", "cls_normalized")):
+        np.testing.assert_allclose(oe.forward(sp, w, ids, mask, pool=pool), np.asarray(g[key]), rtol=0, atol=2e-5)
