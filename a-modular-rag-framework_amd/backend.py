@@ -152,7 +152,7 @@ class DenseRetrievalBackend:
                  text_search: Optional[Callable[..., List[Dict[str, Any]]]] = None,
                  graph_expand: Optional[Callable[..., List[Dict[str, Any]]]] = None,
                  text_channel: Optional[str] = None, bm25_k1: float = 1.5, bm25_b: float = 0.75,
-                 fuse_on_device: bool = False):
+                 fuse_on_device: bool = False, bulk_ingest: bool = True, bulk_batch: int = 4096):
         self.router, self.sink = router, sink
         self.index_path = index_path
         self.alpha_text, self.alpha_graph, self.alpha_dense = float(alpha_text), float(alpha_graph), float(alpha_dense)
@@ -163,6 +163,11 @@ class DenseRetrievalBackend:
         # docs.jsonl, on the device (mrag_amd.text_index), built once per file and shared process-wide
         self.text_channel, self.bm25_k1, self.bm25_b = text_channel, float(bm25_k1), float(bm25_b)
         self.fuse_on_device = bool(fuse_on_device)     # a7's arithmetic in one launch (mrag_fuse_topk) instead of host Python
+        # corpus ingest: when the provider the router resolves can embed in bulk on the device (``embed_device``), the
+        # index is built from docs.jsonl through it in ``bulk_batch``-passage batches (text_index.py:32-53: the reference
+        # builds its index from the file in one go); the router path below stays as the fallback / error-policy reference
+        self.bulk_ingest, self.bulk_batch = bool(bulk_ingest), int(bulk_batch)
+        self.last_build: Dict[str, Any] = {}
         if text_channel not in (None, "bm25"):
             raise ValueError(f"unknown text_channel {text_channel!r} (supported: 'bm25')")
         self._state = None
@@ -191,8 +196,40 @@ class DenseRetrievalBackend:
             out.append(got)
         return np.concatenate(out, axis=0) if out else np.zeros((0, dim or 0), dtype=np.float32)
 
+    def _bulk_provider(self):
+        """The provider ``router.embed`` would call (llm_router.py:103-115 / retrieval_backend.py:203-206:
+        ``router.providers[policy["embedding_provider"]]``) when it offers the bulk device form, else None."""
+        if not self.bulk_ingest:
+            return None
+        try:
+            policy = getattr(self.router, "policy", {}) or {}
+            name = policy.get("embedding_provider")
+            prov = (getattr(self.router, "providers", {}) or {}).get(name) if name else None
+            return prov if prov is not None and hasattr(prov, "embed_device") else None
+        except Exception:
+            return None
+
+    def _bulk_build(self, prov, ix, texts: List[str], dim: int) -> None:
+        """texts -> encoder (large length-sorted batches) -> DenseIndex.add, device to device.  Validated like the
+        router path (row count, dim, finite, not all-zero) chunk by chunk BEFORE the rows enter the index."""
+        import torch
+        step = 65536
+        for lo in range(0, len(texts), step):
+            chunk = texts[lo:lo + step]
+            emb = prov.embed_device(chunk, batch_size=self.bulk_batch)
+            if tuple(emb.shape) != (len(chunk), dim):
+                raise ValueError(f"bulk embed at row {lo}: expected {(len(chunk), dim)}, got {tuple(emb.shape)}")
+            ok = torch.stack([torch.isfinite(emb).all(), emb.any()]).cpu().tolist()      # one sync per 65 536 rows
+            if not ok[0]:
+                raise ValueError(f"bulk embed at row {lo}: non-finite values")
+            if not ok[1]:
+                raise ValueError(f"bulk embed at row {lo}: all-zero vectors")
+            ix.add(emb)                                                                    # K1: fp64 norm, ONE rounding
+
     def _build_state(self, model_hint: str, trace_id: str):
+        import time
         from .index import DenseIndex
+        t_start = time.perf_counter()
         rows = _corpus.read_docs_jsonl(self.index_path)
         state = {"rows": rows, "index": None, "dim": 0, "row_of": {}}
         if not rows:
@@ -216,9 +253,20 @@ class DenseRetrievalBackend:
             for lo in range(0, len(rows), step):
                 ix.add_stored_bits(np.ascontiguousarray(bits[lo:lo + step]))
         else:
-            emb = self._embed_texts(texts, model_hint, trace_id, dim=dim)
-            for lo in range(0, len(rows), step):
-                ix.add(np.ascontiguousarray(emb[lo:lo + step]))       # K1: fp64 norm, ONE rounding
+            prov, how = self._bulk_provider(), "router"
+            if prov is not None:
+                try:
+                    self._bulk_build(prov, ix, texts, dim)
+                    how = "bulk"
+                except Exception as e:          # the router path is the reference behaviour: fall back to it, loudly
+                    logger.error("[DenseRetrievalBackend] bulk ingest failed (%s); rebuilding through router.embed", e)
+                    ix.close()
+                    ix = DenseIndex(dim, metric="cosine", dtype=self.index_dtype, device=self.device)
+            if how == "router":
+                emb = self._embed_texts(texts, model_hint, trace_id, dim=dim)
+                for lo in range(0, len(rows), step):
+                    ix.add(np.ascontiguousarray(emb[lo:lo + step]))       # K1: fp64 norm, ONE rounding
+            state["ingest"] = how
             if cache is not None:
                 cache.store(key, ix.stored_bits(), {"model": model_hint, "rows": len(rows), "dim": dim,
                                                     "dtype": self.index_dtype, "format": "storage bits (uint16)",
@@ -236,6 +284,8 @@ class DenseRetrievalBackend:
             if seen[hid] == 1:
                 row_of[hid] = i
         state["row_of"] = row_of
+        self.last_build = {"rows": len(rows), "dim": dim, "ingest": state.get("ingest", "cache"),
+                           "seconds": time.perf_counter() - t_start}
         return state
 
     def _bm25_searcher(self):

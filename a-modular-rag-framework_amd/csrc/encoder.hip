@@ -1149,6 +1149,11 @@ static int upload_f32(const float* src, int is_device, int64_t n, float* dst, hi
 
 // development switch (MRAG_ENC_GEMM128=1): force the 128 x 128 kernel, for A/B timing
 static const int g_stagger_override = [] { const char* e = getenv("MRAG_ENC_STAGGER"); return e ? atoi(e) : 0; }();   // experiment knob
+static int device_cus() {   // CU count of the current device, read once
+  static int n = 0;
+  if (!n) { hipDeviceProp_t pr; int dev = 0; n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  return n;
+}
 static const bool g_force_gemm128 = [] { const char* e = getenv("MRAG_ENC_GEMM128"); return e && atoi(e) != 0; }();
 
 template <int DT, int NFR>
@@ -1171,8 +1176,7 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
   }
   // 256 x 256 tiles only when they fill the chip: a small batch (the reference embeds one question, then candidates 50 at a
   // time) leaves most CUs idle with 9-72 such tiles, the 128 x 128 kernel gives it four times the workgroups
-  static int n_cus = 0;
-  if (!n_cus) { hipDeviceProp_t pr; int dev = 0; n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  const int n_cus = device_cus();
   const bool fills = (int64_t)(M_pad / G2_T) * (l.N_pad / G2_T) >= n_cus / 2;
   if (M_pad % G2_T == 0 && l.N_pad % G2_T == 0 && fills && !g_force_gemm128) {
     typedef void (*Fn)(const uint16_t*, const uint16_t*, const float*, const uint16_t*, uint16_t*, int, int, int, int, int, LnArgs);
@@ -1184,8 +1188,7 @@ static int run_gemm(const uint16_t* A, const Linear& l, const uint16_t* R, uint1
       attr_done[(const void*)fn] = true;
     }
     const int tm2 = M_pad / G2_T, tn2 = l.N_pad / G2_T;
-    int cus = 256;
-    { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+    const int cus = device_cus();
     const int nwg = std::min(tm2 * tn2, cus);
     const int per_wg = (tm2 * tn2 + nwg - 1) / nwg;
     // (experiment knob, off by default: starting the XCDs an eighth of a tile apart did NOT shorten the store phase --
@@ -1215,8 +1218,7 @@ static int run_gemm_ln(const uint16_t* A, const uint16_t* W, const float* bias, 
   static bool attr_done = false;
   if (!attr_done) { MRAG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS)); attr_done = true; }
   const int tm2 = M_pad / G2_T, tn2 = N_pad / G2_T;
-  int cus = 256;
-  { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+  const int cus = device_cus();   // (cached: this launcher runs ~48 times per bge-base forward)
   const int nwg = std::min(tm2 * tn2, cus);
   hipLaunchKernelGGL((enc_gemm256_kernel<DT, EPI, LNF>), dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, W, bias, R, C, N, K, tm2, tn2, 0, ln);
   MRAG_HIP(hipGetLastError());
@@ -1290,9 +1292,9 @@ static int forward_impl(Encoder* e, int B, int S, float* d_out, int pool, int no
   // run as kernels -- the GEMM before one emits per-token partial sums, a tiny kernel turns them into (mu, rstd), and the GEMMs
   // after it take the PRE-LayerNorm tensor as operand / residual (LnArgs above).  Only the last layer's output LayerNorm is
   // materialised, for the pooling.  MRAG_ENC_NO_FUSED_LN=1 keeps the plain flow (A/B, and the path small batches always take).
-  static const bool fused_off = [] { const char* v = getenv("MRAG_ENC_NO_FUSED_LN"); return v && atoi(v) != 0; }();
-  static int n_cus_f = 0;
-  if (!n_cus_f) { hipDeviceProp_t pr; int dev = 0; n_cus_f = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  // (read per forward, not once per process: the A/B test flips it between two calls)
+  const bool fused_off = [] { const char* v = getenv("MRAG_ENC_NO_FUSED_LN"); return v && atoi(v) != 0; }();
+  const int n_cus_f = device_cus();
   const bool fused = !fused_off && !g_force_gemm128 && M_pad % G2_T == 0 && H % 16 == 0 && round_up(H, G2_T) / G2_T * (M_pad / G2_T) >= n_cus_f / 2;
   uint16_t *y1 = y, *y2 = nullptr;
   float2 *st1 = nullptr, *st2 = nullptr;

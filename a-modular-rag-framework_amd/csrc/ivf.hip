@@ -40,7 +40,7 @@ struct IvfIndex : Object {
   DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
   bool last_scores_path = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | list scan begin | list scan end | search end
-  bool timed = false;
+  bool timed = false, end_recorded = false;
   int last_n_wg = 0;
   ~IvfIndex() override {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -563,6 +563,10 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   }
   if (nq > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF batch (2^20); cut the query batch");
   ix->timed = false;
+  // an asynchronous search (device queries + device results) returns with the handle's scratch buffers still in use on ITS
+  // stream; a following search on another stream first waits for that one's end event (a no-op on the same stream or after a
+  // synchronous search), so callers may switch streams between searches on one handle
+  if (ix->end_recorded) MRAG_HIP(hipStreamWaitEvent(stream, ix->ev[3], 0));
   MRAG_HIP(hipEventRecord(ix->ev[0], stream));
 
   float* d_sc = out_scores;
@@ -704,6 +708,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   }
   ix->last_scores_path = use_scores;
   MRAG_HIP(hipEventRecord(ix->ev[3], stream));
+  ix->end_recorded = true;
   ix->last_n_wg = n_wg;
   ix->timed = true;
   if (!out_is_device) {

@@ -237,6 +237,26 @@ class HipSentenceEncoder:
                                                N.POOL_CLS if pool == "cls" else N.POOL_MEAN, int(bool(normalize)), 0, None))
         return out
 
+    def forward_device(self, ids, mask, out=None, pool: Optional[str] = None, normalize: bool = True, stream=None):
+        """The same forward with ids / mask (int32 CUDA tensors [B,S]) and the result (float32 CUDA tensor
+        [B,hidden]) in HBM -- ``io_is_device`` of ``mrag_encoder_forward``: nothing crosses PCIe but the ids, and
+        the rows can go straight into ``DenseIndex.add`` (bulk ingest).  Asynchronous on ``stream`` (default: torch's
+        current stream)."""
+        import torch
+        ids = ids.contiguous(); mask = mask.contiguous()
+        if ids.dtype != torch.int32 or mask.dtype != torch.int32 or not ids.is_cuda or not mask.is_cuda:
+            raise ValueError("forward_device expects int32 CUDA tensors")
+        B, S = ids.shape
+        if out is None:
+            out = torch.empty((B, self.spec.hidden), dtype=torch.float32, device=ids.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        pool = pool or self.spec.pool
+        N.check(self._lib.mrag_encoder_forward(self._h, ids.data_ptr(), mask.data_ptr(), B, S, out.data_ptr(),
+                                               N.POOL_CLS if pool == "cls" else N.POOL_MEAN, int(bool(normalize)), 1,
+                                               int(getattr(stream, "cuda_stream", stream))))
+        return out
+
     def last_timing_ms(self) -> float:
         """Device ms of the last forward's kernels (``mrag_encoder_last_timing``)."""
         ms = C.c_float(0)
@@ -254,6 +274,53 @@ class HipSentenceEncoder:
             ids[i, :len(s)] = s
             mask[i, :len(s)] = 1
         return ids, mask
+
+    def encode_device(self, texts: List[str], batch_size: int = 4096, normalize: bool = True, out=None):
+        """Texts -> float32 CUDA tensor [n, hidden], rows in input order (bulk ingest: large length-sorted batches so
+        that the 256 x 256 / fused-LayerNorm GEMM flow runs, no host copy of the embeddings, no Python float lists).
+        A tokeniser thread prepares batch i+1 while the GPU runs batch i; every batch's rows are scattered to their
+        input positions on the device.  ``out``: an existing [n, hidden] float32 CUDA tensor to fill."""
+        import queue
+        import threading
+        import torch
+        n = len(texts)
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.empty((n, self.spec.hidden), dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        order = sorted(range(n), key=lambda i: len(texts[i]))
+        batches = [order[lo:lo + batch_size] for lo in range(0, n, batch_size)]
+        ready: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def produce():
+            try:
+                for sel in batches:
+                    ids, mask = self.tokenize([texts[i] for i in sel])
+                    ready.put((sel, ids, mask))
+                ready.put(None)
+            except BaseException as e:
+                ready.put(e)
+        t = threading.Thread(target=produce, name="mrag-tokenizer", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                sel, ids, mask = item
+                rows = self.forward_device(torch.from_numpy(ids).to(dev, non_blocking=True),
+                                           torch.from_numpy(mask).to(dev, non_blocking=True), normalize=normalize)
+                out.index_copy_(0, torch.as_tensor(sel, dtype=torch.int64, device=dev), rows)
+        finally:
+            while t.is_alive():
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    t.join(0.01)
+        return out
 
     def encode(self, texts: List[str], batch_size: int = 256, normalize: bool = True, overlap: bool = True) -> np.ndarray:
         """Texts -> [n, hidden] float32.  Batches are formed in length order (less padding) and the rows are

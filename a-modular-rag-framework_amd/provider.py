@@ -80,6 +80,16 @@ class HipEmbeddingProvider:
         return enc.encode([t if isinstance(t, str) else str(t) for t in texts], batch_size=int(self.kwargs["batch_size"]),
                           normalize=bool(enc.normalize_default if norm is None else norm))
 
+    def embed_device(self, texts: List[str], batch_size: Optional[int] = None):
+        """Bulk form for corpus ingest (``DenseRetrievalBackend``'s fast path): [n, d] float32 rows as a CUDA tensor in
+        input order, embedded in large length-sorted batches (default 4096 passages) -- no ``.tolist()`` round trip,
+        no host copy; the rows go device -> device into ``DenseIndex.add``."""
+        enc = self.encoder
+        norm = self.kwargs["normalize"]
+        return enc.encode_device([t if isinstance(t, str) else str(t) for t in texts],
+                                 batch_size=int(batch_size or self.kwargs.get("bulk_batch_size") or 4096),
+                                 normalize=bool(enc.normalize_default if norm is None else norm))
+
     def embed(self, texts: Optional[List[str]] = None, *, model: Optional[str] = None,
               require: Optional[Dict[str, Any]] = None, **kw) -> Dict[str, Any]:
         vecs = self.embed_array(list(texts or []))

@@ -100,11 +100,12 @@ def k2_roofline(ix, queries, k, n_rows, d, iters=20, warm=3, label=""):
             "flop_per_launch": flop, "timing": f"median of {iters} launches"}
 
 
-def ivf_leg(device, k):
-    """C5 on one GPU's share: 625 000 x 768 clustered rows, nlist 4096 (device k-means), nprobe 32, 10 k queries."""
+def ivf_leg(device, k, n=625_000, with_cpu=False):
+    """C5: n x 768 clustered rows (625 000 = one GPU's share of the 5 M corpus; 5 000 000 = the whole corpus on one
+    GPU, the N = 1 point of C5's scaling curve), nlist 4096 (device k-means), nprobe 32, 10 k queries."""
     import torch
     from mrag_amd.index import IVFFlatIndex, DenseIndex
-    n, d, nlist, nprobe, nq = 625_000, DIM, 4096, 32, N_QUERIES
+    d, nlist, nprobe, nq = DIM, 4096, 32, N_QUERIES
     g = torch.Generator(device=device).manual_seed(1)
     cent = torch.randn(4096, d, device=device, generator=g)
     ix, bf = IVFFlatIndex(d, nlist, device=device.index), DenseIndex(d, device=device.index)
@@ -124,14 +125,32 @@ def ivf_leg(device, k):
         scan.append(t["scan_ms"]); tot.append(t["total_ms"])
     bs, bi = bf.search(q, k)
     torch.cuda.synchronize()
+    bf_ms = bf.last_timing_ms()[1]
     ids, bi = ids.cpu().numpy(), bi.cpu().numpy()
     rec = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, bi)]))
     scan_ms, tot_ms = float(np.median(scan)), float(np.median(tot))
     nbytes = t["scanned_rows"] * d * 2.0
     ach = nbytes / (scan_ms * 1e-3) / 1e9
+    cpu = None
+    if with_cpu:
+        # this leg's CPU baseline: the numpy restatement of IVF-flat (oracle.dense_search.ivf_search: fp64 probe
+        # selection + exact scan of the probed lists) on the GPU's own centroids / assignments, bounded query sample
+        from oracle import dense_search as ods
+        c16 = np.empty((n, d), dtype=np.float16)
+        for lo in range(0, n, 125_000):
+            c16[lo:lo + 125_000] = bf.rows(lo, min(125_000, n - lo))
+        cen, asg = ix.centroids().astype(np.float16), ix.assignments().astype(np.int64)
+        q16 = ods.normalize_round(q[:256].cpu().numpy())
+        t1 = time.perf_counter(); ods.ivf_search(q16[:8], c16, cen, asg, nprobe, k); probe = time.perf_counter() - t1
+        ns = int(min(256, max(8, 10.0 / max(probe / 8, 1e-6))))
+        t1 = time.perf_counter(); ods.ivf_search(q16[:ns], c16, cen, asg, nprobe, k); cpu_s = time.perf_counter() - t1
+        cpu = {"value": ns / cpu_s, "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": f"{ns} of the {nq} queries, numpy fp64 IVF-flat (probe selection + exact scan of {nprobe} lists) over the "
+                         f"same {n} rows / centroids / assignments, {cpu_s:.1f} s (per-query loop: one core + BLAS gemv)"}
+        del c16
     ix.close(); bf.close()
-    return {"bound": "hbm", "kernel": "ivfs_scan_kernel + ivfs_select_lists_kernel (IVF list scan: fp32 score segments, then the k best per query)",
-            "workload": f"C5 per-GPU share: {n} x {d} fp16, nlist {nlist}, nprobe {nprobe}, {nq} queries, k={k}, clustered rows",
+    return {"bound": "hbm", "cpu_baseline": cpu, "brute_force_search_ms": bf_ms, "kernel": "ivfs_scan_kernel + ivfs_select_lists_kernel (IVF list scan: fp32 score segments, then the k best per query)",
+            "workload": f"C5 {'per-GPU share' if n < 5_000_000 else 'whole corpus on one GPU'}: {n} x {d} fp16, nlist {nlist}, nprobe {nprobe}, {nq} queries, k={k}, clustered rows",
             "kernel_ms": scan_ms, "search_ms": tot_ms, "queries_per_s": nq / (tot_ms * 1e-3),
             "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
             "bytes_per_launch": nbytes, "rows_streamed": t["scanned_rows"], "workgroups": t["n_wg"],
@@ -141,7 +160,51 @@ def ivf_leg(device, k):
                     "4 B per (query, row) score out and back: about twice the algorithmic bytes"}
 
 
-def encoder_leg(device):
+def ivf_skewed_leg(device, k):
+    """the clustered C5 data above (centroid + 0.3 N(0,I) in 768 dimensions) is trivially separable and its
+    lists are balanced -- the best case.  This leg: Zipf-like cluster popularity (list sizes spread over ~100x) and
+    overlapping clusters (sigma = 1.0: noise norm = centroid norm), queries = a corpus row + 0.7 N(0,I); recall@10
+    against exact brute force and the search time as nprobe grows."""
+    import torch
+    from mrag_amd.index import IVFFlatIndex, DenseIndex
+    n, d, nlist, nq = 625_000, DIM, 4096, N_QUERIES
+    g = torch.Generator(device=device).manual_seed(7)
+    cent = torch.randn(nlist, d, device=device, generator=g)
+    pop = 1.0 / torch.arange(1, nlist + 1, device=device, dtype=torch.float32) ** 0.8
+    ix, bf = IVFFlatIndex(d, nlist, device=device.index), DenseIndex(d, device=device.index)
+
+    def draw(m):
+        c = torch.multinomial(pop, m, replacement=True, generator=g)
+        return cent[c] + 1.0 * torch.randn(m, d, device=device, generator=g)
+    ix.train(draw(100_000), iters=5, seed=1)
+    keep = []
+    for lo in range(0, n, 125_000):
+        rows = draw(125_000)
+        ix.add(rows); bf.add(rows)
+        keep.append(rows[:2000].clone())
+    pool = torch.cat(keep)
+    q = pool[torch.randint(0, pool.shape[0], (nq,), device=device, generator=g)] + 0.7 * torch.randn(nq, d, device=device, generator=g)
+    counts = np.bincount(ix.assignments(), minlength=nlist)
+    bs, bi = bf.search(q, k)
+    torch.cuda.synchronize()
+    bi = bi.cpu().numpy()
+    pts = []
+    for nprobe in (1, 4, 8, 32, 128):
+        ix.search(q, k, nprobe)
+        ms = []
+        for _ in range(3):
+            sc, ids = ix.search(q, k, nprobe)
+            ms.append(ix.last_timing()["total_ms"])
+        ids = ids.cpu().numpy()
+        rec = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(ids, bi)]))
+        pts.append({"nprobe": nprobe, "recall_at_10": rec, "search_ms": float(np.median(ms)), "rows_streamed": ix.last_timing()["scanned_rows"]})
+    ix.close(); bf.close()
+    return {"workload": f"{n} x {d} fp16, nlist {nlist}, Zipf(0.8) cluster popularity, sigma 1.0 (overlapping clusters), {nq} queries, k={k}",
+            "list_rows_max": int(counts.max()), "list_rows_median": float(np.median(counts)), "list_rows_min": int(counts.min()),
+            "points": pts}
+
+
+def encoder_leg(device, with_cpu=False):
     """C3 shape: bge-base (12 x 768, 12 heads, FFN 3072, 30 522-row vocabulary), 2048 passages x 128 tokens."""
     from mrag_amd.encoder import HipSentenceEncoder, ARCHS
     arch, B, S = "bge-base", 2048, 128
@@ -160,12 +223,73 @@ def encoder_leg(device):
     flop_tok = 2.0 * a["layers"] * (4 * a["hidden"] ** 2 + 2 * a["hidden"] * a["intermediate"]) + 4.0 * S * a["hidden"] * a["layers"]
     ms = float(np.median(dev_ms))
     ach = B * S * flop_tok / (ms * 1e-3) / 1e12
+    cpu = None
+    if with_cpu:
+        # this leg's CPU baseline: the numpy fp64 restatement of the BERT forward (oracle.encoder.forward, pinned to HF
+        # BertModel by F6 / F9) on a few of the same passages with the same seeded weights
+        from oracle import encoder as oenc
+        from mrag_amd.encoder import seeded_weights, EncoderSpec
+        w = seeded_weights(EncoderSpec(**a), 0)
+        spec = {k_: a[k_] for k_ in ("vocab_size", "hidden", "layers", "heads", "intermediate", "max_position", "type_vocab_size", "layer_norm_eps")}
+        nb = 4
+        t1 = time.perf_counter(); ref = oenc.forward(spec, w, ids[:nb].astype(np.int64), mask[:nb].astype(np.int64), pool=a["pool"]); cpu_s = time.perf_counter() - t1
+        got = enc.forward(ids[:nb], mask[:nb])
+        cpu = {"value": nb / cpu_s, "unit": "passages/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"{nb} of the {B} passages x {S} tokens, numpy fp64 BERT forward (BLAS threads), {cpu_s:.1f} s",
+               "max_abs_diff_gpu_vs_cpu": float(np.abs(got - ref).max())}
     enc.close()
-    return {"bound": "mfma", "kernel": "enc_gemm256_kernel (LayerNorm folded into its epilogues) + enc_attention_s128_kernel (whole forward)",
+    return {"bound": "mfma", "cpu_baseline": cpu, "kernel": "enc_gemm256_kernel (LayerNorm folded into its epilogues) + enc_attention_s128_kernel (whole forward)",
             "workload": f"C3 shape: {arch}, {B} passages x {S} tokens, seeded weights",
             "device_ms": ms, "host_call_ms": float(np.median(wall_ms)), "passages_per_s": B / (ms * 1e-3),
             "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_F16,
             "flop_per_token": flop_tok}
+
+
+def synthetic_sentences(n: int, seed: int = 0):
+    """HotpotQA-shaped passages (one sentence per corpus row, my_code/ingest_hotpotqa.py:73-81): 3 .. 80 words, mean ~ 25."""
+    rng = np.random.default_rng(seed)
+    vocab = np.array([f"w{i}" for i in range(20000)])
+    lens = np.clip(rng.normal(25, 10, size=n).astype(np.int64), 3, 80)
+    words = vocab[rng.integers(0, len(vocab), size=int(lens.sum()))]
+    out, at = [], 0
+    for L in lens:
+        out.append(" ".join(words[at:at + L]))
+        at += L
+    return out
+
+
+def ingest_leg(device, n=65_536):
+    """texts -> index: C3's 64 k passages through the provider's bulk device form (tokenise on the host,
+    overlapped; bge-base forward in large length-sorted batches; rows device -> device into DenseIndex.add / K1)."""
+    import torch
+    from mrag_amd.provider import HipEmbeddingProvider
+    from mrag_amd.index import DenseIndex
+    texts = synthetic_sentences(n)
+    prov = HipEmbeddingProvider(arch="bge-base", seed=0, device=device.index)
+    enc = prov.encoder
+    t0 = time.perf_counter()
+    ids, mask = enc.tokenize(texts[:8192])
+    tok_s = (time.perf_counter() - t0) * n / 8192
+    prov.embed_device(texts[:4096])                      # warm-up (kernel load, buffers)
+    ix = DenseIndex(enc.spec.hidden, device=device.index)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = prov.embed_device(texts, batch_size=4096)
+    ix.add(emb)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the router-shaped path on a bounded sample: embed() 256 texts at a time -> python float lists -> numpy -> host add
+    m = 4096
+    t0 = time.perf_counter()
+    for lo in range(0, m, 256):
+        v = np.asarray(prov.embed(model="x", texts=texts[lo:lo + 256])["vectors"], dtype=np.float32)
+    rt = time.perf_counter() - t0
+    ix.close()
+    return {"workload": f"{n} synthetic HotpotQA-shaped sentences (mean {int(mask.sum() / 8192)} tokens) -> bge-base (seeded) -> DenseIndex",
+            "passages_per_s_from_text": n / dt, "seconds": dt, "tokenise_seconds_if_serial": tok_s,
+            "router_path_passages_per_s": m / rt,
+            "note": "bulk: provider.embed_device (4096-passage length-sorted batches, tokeniser thread overlapped) + DenseIndex.add "
+                    "device to device; router path: provider.embed 256 texts per call (lists of Python floats), timed on 4096 passages"}
 
 
 def main():
@@ -178,6 +302,7 @@ def main():
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the north-star / C2 / IVF / encoder sub-objects")
+    ap.add_argument("--skip-legs", default="", help="comma list of sub-objects to skip (e.g. ivf_roofline_5m,ingest_from_text): counter passes")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -420,7 +545,13 @@ def main():
             del c32
         if world == 1 and not args.no_extras:
             sh.index.close()                                       # free the 1.5 GB corpus before the other configs
-            for name, leg in (("ivf_roofline", lambda: ivf_leg(device, k)), ("encoder_roofline", lambda: encoder_leg(device))):
+            for name, leg in (("ivf_roofline", lambda: ivf_leg(device, k, with_cpu=not args.no_cpu)),
+                              ("ivf_roofline_5m", lambda: ivf_leg(device, k, n=5_000_000)),
+                              ("ivf_skewed", lambda: ivf_skewed_leg(device, k)),
+                              ("encoder_roofline", lambda: encoder_leg(device, with_cpu=not args.no_cpu)),
+                              ("ingest_from_text", lambda: ingest_leg(device))):
+                if name in args.skip_legs.split(","):
+                    continue
                 try:
                     out[name] = leg()
                 except Exception as e:                             # a sub-object must never cost the headline line

@@ -107,6 +107,36 @@ def test_fused_layernorm_flow_matches_oracle(arch, B, S, pool, layers):
         np.testing.assert_allclose(enc16.forward(ids, mask, pool=pool)[sub], want, rtol=0, atol=8e-3)
 
 
+def test_fused_layernorm_flow_on_offset_and_outlier_activations(monkeypatch):
+    """the fused flow computes per-token variance as E[x^2] - mean^2 in fp32 from the rounded GEMM outputs and
+    evaluates ``rstd (y W'^T - mu s) + c``: both cancel when a token's activations share a large common offset or carry
+    outlier dimensions (what trained BERT-family models do).  Same ids through the fused flow, the plain flow
+    (MRAG_ENC_NO_FUSED_LN=1) and the oracle, with biases that put +12 on every pre-LayerNorm dimension and +/- 60 on three of
+    them: stored rows / query embeddings must agree whichever flow produced them."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec
+    spec = dict(oe.SPECS["minilm-l6"], vocab_size=3000, max_position=128, layers=2)
+    w = oe.seeded_weights(spec, 77)
+    for i in range(spec["layers"]):
+        for name in (f"encoder.layer.{i}.attention.output.dense.bias", f"encoder.layer.{i}.output.dense.bias"):
+            b = w[name].copy()
+            b += 12.0
+            b[[3, 77, 200]] += np.array([60.0, -60.0, 45.0], dtype=np.float32)
+            w[name] = b
+    enc = HipSentenceEncoder(EncoderSpec(**dict(spec, max_length=128)), w)
+    ids, mask = _batch(spec, 512, 32, 23)
+    monkeypatch.delenv("MRAG_ENC_NO_FUSED_LN", raising=False)
+    fused = enc.forward(ids, mask, pool="mean")
+    monkeypatch.setenv("MRAG_ENC_NO_FUSED_LN", "1")
+    plain = enc.forward(ids, mask, pool="mean")
+    monkeypatch.delenv("MRAG_ENC_NO_FUSED_LN")
+    sub = np.arange(0, 512, 32)
+    want = oe.forward(spec, w, ids[sub], mask[sub], pool="mean")
+    d_fp, d_fo, d_po = np.abs(fused - plain).max(), np.abs(fused[sub] - want).max(), np.abs(plain[sub] - want).max()
+    print(f"offset/outlier activations: |fused - plain| {d_fp:.2e}, |fused - oracle| {d_fo:.2e}, |plain - oracle| {d_po:.2e}")
+    assert np.isfinite(fused).all() and not np.array_equal(fused, plain)      # (the two flows did run)
+    assert d_po <= 2e-3 and d_fo <= 2e-3 and d_fp <= 2e-3
+
+
 @pytest.mark.parametrize("case", ["minilm2", "bge1"])
 def test_f6_hf_golden(golden_dir, case):
     """F6: the committed HF BertModel outputs (tests/golden/make_golden_encoder.py) -- MiniLM-L6 / bge-base layer
@@ -225,3 +255,65 @@ def test_f9_provider_from_model_directory(golden_dir):
     for row, m, want in zip(ids, mask, g["ids"]):
         assert row[m.astype(bool)].tolist() == want
     np.testing.assert_allclose(enc.forward(ids, mask, pool="cls"), np.asarray(g["cls_normalized"]), rtol=0, atol=TOL)
+
+
+def _synthetic_docs(path, n_titles, seed):
+    from mrag_amd import corpus
+    rng = np.random.default_rng(seed)
+    vocab = [f"w{i}" for i in range(400)] + ["alpha", "beta", "gamma", "delta", "river", "city", "born", "film", "band", "album"]
+    rows = []
+    for t in range(n_titles):
+        for sid in range(int(rng.integers(1, 6))):
+            rows.append({"doc_id": f"Title {t}#{sid}", "title": f"Title {t}", "sent_id": sid,
+                         "text": " ".join(rng.choice(vocab, size=int(rng.integers(3, 40))))})
+    corpus.write_docs_jsonl(path, rows)
+    return rows
+
+
+def test_bulk_ingest_matches_the_router_path(tmp_path):
+    """the corpus index built from docs.jsonl through the provider's bulk device form (large
+    length-sorted batches, device -> device into DenseIndex.add) against the index built through ``router.embed``
+    256 texts at a time (the reference-shaped path, kept as the fallback).  Batch composition selects the padded
+    sequence length and the GEMM flow, so the two are equal up to the encoder's fp16 noise, not bit for bit: stored
+    rows within 1e-3 (the encoder's own tolerance), the same top-10 outside near-ties."""
+    from mrag_amd.backend import DenseRetrievalBackend
+    from mrag_amd.provider import HipEmbeddingProvider
+    docs = tmp_path / "docs.jsonl"
+    rows = _synthetic_docs(docs, 1700, 3)
+    assert len(rows) >= 5000
+    prov = HipEmbeddingProvider(arch="small", seed=7, embed_model="small-seed7")
+
+    class Router:
+        providers, policy = {"hip": prov}, {"embedding_provider": "hip"}
+        calls = 0
+        def embed(self, *, model_hint, texts, require=None):
+            Router.calls += 1
+            return rs.router_embed(self.providers, self.policy, model_hint=model_hint, texts=texts, require=require)
+    fast = DenseRetrievalBackend(Router(), index_path=str(docs), bulk_ingest=True, bulk_batch=2048)
+    st_fast = fast._build_state("small-seed7", "t")
+    calls_fast = Router.calls
+    slow = DenseRetrievalBackend(Router(), index_path=str(docs), bulk_ingest=False)
+    st_slow = slow._build_state("small-seed7", "t")
+    assert st_fast["ingest"] == "bulk" and st_slow["ingest"] == "router"
+    assert calls_fast == 1 and Router.calls - calls_fast >= 1 + len(rows) // 256     # bulk: only the 1-text dim probe
+    assert fast.last_build["ingest"] == "bulk" and fast.last_build["rows"] == len(rows)
+    a, b = st_fast["index"].rows(), st_slow["index"].rows()
+    assert a.shape == b.shape == (len(rows), 128)
+    assert float(np.abs(a - b).max()) <= TOL
+    np.testing.assert_allclose(np.linalg.norm(a, axis=1), 1.0, atol=2e-3)
+    q = prov.embed_array(["gamma river born w17 w3", "film band album w250"])
+    sa, ia = st_fast["index"].search(q, 10)
+    sb, ib = st_slow["index"].search(q, 10)
+    np.testing.assert_allclose(sa, sb, rtol=0, atol=2e-3)
+    assert ds.gap_aware_id_match(ia, sa, ib, sb.astype(np.float64), tol=4e-3)[1] == 0
+    # a provider whose bulk form fails falls back to the router path and still builds the index
+    class Broken(HipEmbeddingProvider):
+        def embed_device(self, texts, batch_size=None):
+            raise RuntimeError("no bulk today")
+    bprov = Broken(arch="small", seed=7, embed_model="small-seed7")
+    class Router2(Router):
+        providers = {"hip": bprov}
+    st_fb = DenseRetrievalBackend(Router2(), index_path=str(docs))._build_state("small-seed7", "t")
+    assert st_fb["ingest"] == "router" and len(st_fb["index"]) == len(rows)
+    for st in (st_fast, st_slow, st_fb):
+        st["index"].close()
