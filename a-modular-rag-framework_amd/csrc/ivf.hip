@@ -39,13 +39,16 @@ struct IvfIndex : Object {
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
   DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
   bool last_scores_path = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | list scan begin | list scan end | search end
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | (unused) | (unused) | search end
+  std::vector<hipEvent_t> cev;    // per chunk of the last search: list scan begin, list scan end
+  int n_chunks = 0;               // chunks of the last search (mrag_ivf_last_timing sums their scan brackets)
+  DevBuf stats;                   // device accumulators of the last search: int64 rows streamed by the list scans, int64 workgroups
   bool timed = false, end_recorded = false;
-  int last_n_wg = 0;
   ~IvfIndex() override {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : cev) if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
-    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc}) b->release();
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc, &stats}) b->release();
   }
 };
 
@@ -81,16 +84,19 @@ __global__ void ivf_count_kernel(const int64_t* __restrict__ probes, int64_t npa
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
                                                         const int* __restrict__ list_tile_lo, int nlist,
                                                         int* __restrict__ wg_first, int* __restrict__ cursor,
-                                                        int* __restrict__ desc, int desc_cap, int* __restrict__ n_wg_out) {
+                                                        int* __restrict__ desc, int desc_cap, int* __restrict__ n_wg_out,
+                                                        unsigned long long* __restrict__ stats) {
   __shared__ int part[1024];
   __shared__ int carry;
+  __shared__ unsigned long long rows_acc;
   const int tid = threadIdx.x;
-  if (tid == 0) carry = 0;
+  if (tid == 0) { carry = 0; rows_acc = 0ull; }
   __syncthreads();
   for (int base = 0; base < nlist; base += 1024) {
     const int l = base + tid;
     const int cnt = l < nlist ? lcount[l] : 0;
     const int nt = (cnt + 255) >> 8;
+    if (nt && l < nlist) atomicAdd(&rows_acc, (unsigned long long)nt * (unsigned long long)list_count[l]);
     part[tid] = nt;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {           // inclusive scan (Hillis-Steele)
@@ -121,7 +127,10 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ 
     if (tid == 1023) carry += part[1023];
     __syncthreads();
   }
-  if (tid == 0) *n_wg_out = carry;
+  if (tid == 0) {
+    *n_wg_out = carry;
+    if (stats) { atomicAdd(&stats[0], rows_acc); atomicAdd(&stats[1], (unsigned long long)carry); }
+  }
 }
 
 __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
@@ -153,19 +162,22 @@ __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t n
 __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
                                                                const int* __restrict__ list_tile_lo, int nlist,
                                                                int* __restrict__ wg_first, int* __restrict__ cursor,
-                                                               int* __restrict__ desc, int desc_cap, int* __restrict__ out) {
+                                                               int* __restrict__ desc, int desc_cap, int* __restrict__ out,
+                                                               unsigned long long* __restrict__ stats) {
   __shared__ int part[1024];
   __shared__ long long fpart[1024];
   __shared__ int carry;
   __shared__ long long fcarry;
+  __shared__ unsigned long long rows_acc;
   const int tid = threadIdx.x;
-  if (tid == 0) { carry = 0; fcarry = 0; }
+  if (tid == 0) { carry = 0; fcarry = 0; rows_acc = 0ull; }
   __syncthreads();
   for (int base = 0; base < nlist; base += 1024) {
     const int l = base + tid;
     const int cnt = l < nlist ? lcount[l] : 0;
     const int lc = l < nlist ? list_count[l] : 0;
     const int nt = (cnt + IVFS_QUERIES - 1) / IVFS_QUERIES;
+    if (nt && lc) atomicAdd(&rows_acc, (unsigned long long)nt * (unsigned long long)lc);   // rows this list's workgroups stream
     const int pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
     const long long fl = (long long)cnt * pitch;
     part[tid] = nt;
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __rest
     out[0] = carry;
     out[1] = (int)(unsigned)(fcarry & 0xFFFFFFFFll);
     out[2] = (int)(fcarry >> 32);
+    if (stats) { atomicAdd(&stats[0], rows_acc); atomicAdd(&stats[1], (unsigned long long)carry); }
   }
 }
 
@@ -528,46 +541,11 @@ int mrag_ivf_get_assignments(mrag_handle h, int32_t* out, int out_is_device, voi
   return MRAG_OK;
 }
 
-int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize, int queries_is_device, int nprobe,
-                    int k, float* out_scores, int64_t* out_ids, int out_is_device, void* stream_) {
-  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
-  if (!ix) return MRAG_ERR_INVALID;
-  if (nq < 0 || k <= 0 || nprobe <= 0) return fail(MRAG_ERR_INVALID, "bad nq / k / nprobe");
-  if (k > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the fused top-k limit %d", k, bf_max_k());
-  nprobe = std::min(nprobe, ix->nlist);
-  // probe selection = top-nprobe over the centroids: the fused kernel up to 64, the streaming kernel up to 256
-  // (8 queries per launch); nprobe == nlist needs no selection at all
-  if (nprobe > bf_max_k_wide() && nprobe < ix->nlist)
-    return fail(MRAG_ERR_UNSUPPORTED, "nprobe = %d: supported are 1..%d and nlist (= %d, exhaustive)", nprobe, bf_max_k_wide(), ix->nlist);
-  if (nq == 0) return MRAG_OK;
-  if (!queries || !out_scores || !out_ids || !esize(q_dtype)) return fail(MRAG_ERR_INVALID, "bad buffer / dtype");
-  if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "index has no centroids");
-  MRAG_TRY(use_device(ix->device));
-  hipStream_t stream = (hipStream_t)stream_;
-  MRAG_TRY(ivf_finalize(ix, stream));
-  // Large batches are cut so that a chunk's score segments fit the score buffer even if every pair probes the longest
-  // list (ivf_scan.hip's regime, without a host round trip); results are per query, so the chunks are independent.
-  {
-    static const int64_t cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 4096) << 20; }();
-    const int64_t per_query = std::max<int64_t>((int64_t)std::min(nprobe, 256) * ivfs_pitch(ix->max_list_rows), ivfs_pitch(ix->nlist)) * 4;
-    const int64_t chunk = std::max<int64_t>(1024, cap / std::max<int64_t>(per_query, 1) / IVFS_QUERIES * IVFS_QUERIES);
-    if (cap > 0 && nprobe <= 256 && nq > chunk) {
-      const size_t qrow = (size_t)ix->dim * esize(q_dtype);
-      for (int64_t off = 0; off < nq; off += chunk) {
-        const int64_t m = std::min(chunk, nq - off);
-        MRAG_TRY(mrag_ivf_search(h, (const char*)queries + (size_t)off * qrow, m, q_dtype, normalize, queries_is_device, nprobe, k,
-                                 out_scores + (size_t)off * k, out_ids + (size_t)off * k, out_is_device, stream_));
-      }
-      return MRAG_OK;   // (mrag_ivf_last_timing then reports the last chunk)
-    }
-  }
-  if (nq > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF batch (2^20); cut the query batch");
-  ix->timed = false;
-  // an asynchronous search (device queries + device results) returns with the handle's scratch buffers still in use on ITS
-  // stream; a following search on another stream first waits for that one's end event (a no-op on the same stream or after a
-  // synchronous search), so callers may switch streams between searches on one handle
-  if (ix->end_recorded) MRAG_HIP(hipStreamWaitEvent(stream, ix->ev[3], 0));
-  MRAG_HIP(hipEventRecord(ix->ev[0], stream));
+// one chunk of a search (<= 2^20 queries whose score segments fit the buffer): probe selection, plan, list scan, selection
+static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q_dtype, int normalize, int queries_is_device, int nprobe,
+                            int k, float* out_scores, int64_t* out_ids, int out_is_device, hipStream_t stream, int chunk_idx) {
+  hipEvent_t ev_scan0 = ix->cev[2 * chunk_idx], ev_scan1 = ix->cev[2 * chunk_idx + 1];
+  unsigned long long* d_stats = (unsigned long long*)ix->stats.p;
 
   float* d_sc = out_scores;
   int64_t* d_id = out_ids;
@@ -587,7 +565,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   // The list scan (and the probe selection before it) runs as "score segments + select" (ivf_scan.hip) whenever the
   // fp32 segments of this search fit the score buffer; otherwise (exhaustive probing of a big index) as the fused
   // GEMM + top-k kernel in descriptor mode.  MRAG_IVF_SCORES_MB = 0 forces the fused path (tests).
-  static const int64_t scores_cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 4096) << 20; }();
+  static const int64_t scores_cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 16384) << 20; }();
   const int nl = ix->nlist;
   MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
   int* d_lcount = (int*)ix->plan.p;      // queries per list | first workgroup of the list | cursor | workgroup count, score floats
@@ -633,9 +611,10 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
   const int64_t max_pitch = ivfs_pitch(ix->max_list_rows);
   const bool no_sync = use_scores && (int64_t)npairs * max_pitch * 4 <= scores_cap;
   int plan_out[3] = {0, 0, 0};
+  const bool planned_scores = use_scores;
   if (use_scores) {
     hipLaunchKernelGGL(ivf_plan_scores_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
-                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
+                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg, d_stats);
     MRAG_HIP(hipGetLastError());
     if (no_sync) {
       MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>((int64_t)npairs * max_pitch, 4) * 4));
@@ -655,7 +634,7 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
                        (const int*)ix->desc.p, (int4*)ix->ploc.p);
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
-    MRAG_HIP(hipEventRecord(ix->ev[1], stream));
+    MRAG_HIP(hipEventRecord(ev_scan0, stream));
     static const char* stamp_path = getenv("MRAG_IVFS_STAMPS");   // diagnostic builds (MRAG_IVFS_DIAG & 128): per-workgroup clock stamps -> file
     long long* dbg = nullptr;
     if (stamp_path) { MRAG_TRY(ix->qg.ensure((size_t)wg_bound * 64)); MRAG_HIP(hipMemsetAsync(ix->qg.p, 0, (size_t)wg_bound * 64, stream)); dbg = (long long*)ix->qg.p; }
@@ -674,11 +653,12 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
                          (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream));
     }
     MRAG_TRY(ivfs_select_lists((const float*)ix->scores.p, ix->ploc.p, nprobe, nq, k, ix->row_ids, ix->id_base, d_sc, d_id, stream));
-    MRAG_HIP(hipEventRecord(ix->ev[2], stream));
+    MRAG_HIP(hipEventRecord(ev_scan1, stream));
   } else {
     MRAG_HIP(hipMemsetAsync(ix->gq.p, 0xFF, (size_t)wg_bound * 256 * 8, stream));   // (the gather below reads whole 256-slot slabs)
     hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
-                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg);
+                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg,
+                       planned_scores ? nullptr : d_stats);   // (a scores plan that turned out too big has already counted this chunk)
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8,
                        nullptr, nullptr);
@@ -703,18 +683,70 @@ int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype,
     a.id_base = ix->id_base;
     a.out_scores = d_sc; a.out_ids = d_id;
     a.lists = &ix->lists; a.counts = &ix->counts; a.stream = stream;
-    a.ev_k2_begin = ix->ev[1]; a.ev_k2_end = ix->ev[2];
+    a.ev_k2_begin = ev_scan0; a.ev_k2_end = ev_scan1;
     MRAG_TRY(bf_launch(a));
   }
   ix->last_scores_path = use_scores;
-  MRAG_HIP(hipEventRecord(ix->ev[3], stream));
-  ix->end_recorded = true;
-  ix->last_n_wg = n_wg;
-  ix->timed = true;
+  (void)n_wg;
   if (!out_is_device) {
     MRAG_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipMemcpyAsync(out_ids, d_id, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
   }
+  return MRAG_OK;
+}
+
+
+int mrag_ivf_search(mrag_handle h, const void* queries, int64_t nq, int q_dtype, int normalize, int queries_is_device, int nprobe,
+                    int k, float* out_scores, int64_t* out_ids, int out_is_device, void* stream_) {
+  IvfIndex* ix = (IvfIndex*)lookup(h, KIND_IVF);
+  if (!ix) return MRAG_ERR_INVALID;
+  if (nq < 0 || k <= 0 || nprobe <= 0) return fail(MRAG_ERR_INVALID, "bad nq / k / nprobe");
+  if (k > bf_max_k()) return fail(MRAG_ERR_UNSUPPORTED, "k = %d exceeds the fused top-k limit %d", k, bf_max_k());
+  nprobe = std::min(nprobe, ix->nlist);
+  // probe selection = top-nprobe over the centroids: the fused kernel up to 64, the streaming kernel up to 256
+  // (8 queries per launch); nprobe == nlist needs no selection at all
+  if (nprobe > bf_max_k_wide() && nprobe < ix->nlist)
+    return fail(MRAG_ERR_UNSUPPORTED, "nprobe = %d: supported are 1..%d and nlist (= %d, exhaustive)", nprobe, bf_max_k_wide(), ix->nlist);
+  if (nq == 0) return MRAG_OK;
+  if (!queries || !out_scores || !out_ids || !esize(q_dtype)) return fail(MRAG_ERR_INVALID, "bad buffer / dtype");
+  if (!ix->has_centroids) return fail(MRAG_ERR_INVALID, "index has no centroids");
+  MRAG_TRY(use_device(ix->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  MRAG_TRY(ivf_finalize(ix, stream));
+  // Large batches are cut so that a chunk's score segments fit the score buffer even if every pair probes the longest
+  // list (ivf_scan.hip's regime, without a host round trip); results are per query, so the chunks are independent.
+  // Every chunk streams the probed lists again, so the default buffer is generous (16 GiB of the 288: C5's 10 000 x 32
+  // pairs over 5 M rows need 1.6 GB, their no-round-trip bound ~5 GB); MRAG_IVF_SCORES_MB sets it, 0 = fused regime.
+  static const int64_t cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 16384) << 20; }();
+  const int64_t per_query = std::max<int64_t>((int64_t)std::min(nprobe, 256) * ivfs_pitch(ix->max_list_rows), ivfs_pitch(ix->nlist)) * 4;
+  int64_t chunk = std::max<int64_t>(1024, cap / std::max<int64_t>(per_query, 1) / IVFS_QUERIES * IVFS_QUERIES);
+  if (!(cap > 0 && nprobe <= 256 && nq > chunk)) chunk = nq;
+  else chunk = round_up((nq + (nq + chunk - 1) / chunk - 1) / ((nq + chunk - 1) / chunk), IVFS_QUERIES);   // equal chunks
+  if (chunk > (1 << 20)) return fail(MRAG_ERR_UNSUPPORTED, "nq too large for one IVF batch (2^20); cut the query batch");
+  const int n_chunks = (int)((nq + chunk - 1) / chunk);
+  while ((int)ix->cev.size() < 2 * n_chunks) {
+    hipEvent_t e = nullptr;
+    MRAG_HIP(hipEventCreate(&e));
+    ix->cev.push_back(e);
+  }
+  ix->timed = false;
+  // an asynchronous search (device queries + device results) returns with the handle's scratch buffers still in use on ITS
+  // stream; a following search on another stream first waits for that one's end event (a no-op on the same stream or after a
+  // synchronous search), so callers may switch streams between searches on one handle
+  if (ix->end_recorded) MRAG_HIP(hipStreamWaitEvent(stream, ix->ev[3], 0));
+  MRAG_HIP(hipEventRecord(ix->ev[0], stream));
+  MRAG_TRY(ix->stats.ensure(16));
+  MRAG_HIP(hipMemsetAsync(ix->stats.p, 0, 16, stream));
+  const size_t qrow = (size_t)ix->dim * esize(q_dtype);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int64_t off = (int64_t)c * chunk, m = std::min(chunk, nq - off);
+    MRAG_TRY(ivf_search_chunk(ix, (const char*)queries + (size_t)off * qrow, m, q_dtype, normalize, queries_is_device, nprobe, k,
+                              out_scores + (size_t)off * k, out_ids + (size_t)off * k, out_is_device, stream, c));
+  }
+  ix->n_chunks = n_chunks;
+  MRAG_HIP(hipEventRecord(ix->ev[3], stream));
+  ix->end_recorded = true;
+  ix->timed = true;
   // host buffers (pageable query / result memory) must not be touched by the caller before the copies are done; with
   // queries and results in device memory the search is fully asynchronous on `stream`
   if (!out_is_device || !queries_is_device) MRAG_HIP(hipStreamSynchronize(stream));
@@ -727,22 +759,20 @@ int mrag_ivf_last_timing(mrag_handle h, float* out_scan_ms, float* out_total_ms,
   if (!ix->timed) return fail(MRAG_ERR_INVALID, "no completed search to time");
   MRAG_TRY(use_device(ix->device));
   MRAG_HIP(hipEventSynchronize(ix->ev[3]));
+  // a search cut into chunks (score buffer cap) reports the SUM of its chunks' list-scan brackets, rows and workgroups
   float g = 0.f, t = 0.f;
-  MRAG_HIP(hipEventElapsedTime(&g, ix->ev[1], ix->ev[2]));
+  for (int c = 0; c < ix->n_chunks; ++c) {
+    float gc = 0.f;
+    MRAG_HIP(hipEventElapsedTime(&gc, ix->cev[2 * c], ix->cev[2 * c + 1]));
+    g += gc;
+  }
   MRAG_HIP(hipEventElapsedTime(&t, ix->ev[0], ix->ev[3]));
   if (out_scan_ms) *out_scan_ms = g;
   if (out_total_ms) *out_total_ms = t;
-  if (ix->last_n_wg < 0) MRAG_HIP(hipMemcpy(&ix->last_n_wg, (const int*)ix->plan.p + 3 * ix->nlist, 4, hipMemcpyDeviceToHost));   // (left on the device by the search)
-  if (out_n_wg) *out_n_wg = ix->last_n_wg;
-  if (out_scanned_rows) {
-    // rows streamed by the list scan = sum over its workgroups of their list's length (descriptor words 2, 4)
-    std::vector<int> d((size_t)ix->last_n_wg * 8);
-    if (ix->last_n_wg) MRAG_HIP(hipMemcpy(d.data(), ix->desc.p, d.size() * 4, hipMemcpyDeviceToHost));
-    int64_t rows = 0;
-    for (int w = 0; w < ix->last_n_wg; ++w)
-      rows += ix->last_scores_path ? (int64_t)d[(size_t)w * 8 + 3] : (int64_t)d[(size_t)w * 8 + 4] - (int64_t)d[(size_t)w * 8 + 2] * 256;
-    *out_scanned_rows = rows;
-  }
+  unsigned long long st[2] = {0ull, 0ull};
+  MRAG_HIP(hipMemcpy(st, ix->stats.p, 16, hipMemcpyDeviceToHost));   // (accumulated on the device by the plan kernels)
+  if (out_n_wg) *out_n_wg = (int)st[1];
+  if (out_scanned_rows) *out_scanned_rows = (int64_t)st[0];
   return MRAG_OK;
 }
 

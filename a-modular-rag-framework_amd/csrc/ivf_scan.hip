@@ -211,6 +211,271 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
   }
 }
 
+#ifdef MRAG_IVFS_SCAN256
+// ------------------------------------------------------------------ EXPERIMENT (round 3, not built by default): 256-row tiles, ring of three stages
+// make EXTRA=-DMRAG_IVFS_SCAN256 builds it; MRAG_IVFS_SCAN=256 then selects it at run time.  Hypothesis: the kernel above is
+// latency-bound per K step (1.85 us per step whatever it carries), so a 150-row list pays 24 of them (its second 128-row tile
+// holds 24 rows) with one 32-KiB stage in flight per workgroup.  This form:
+//   * one workgroup of 8 waves per CU, tile = 256 corpus rows x 128 queries x K 64: a 129..256-row list is ONE tile
+//     (12 K steps at d = 768 instead of 24), the gathered query rows are fetched once per 256 rows instead of per 128;
+//   * a ring of three 48-KiB stages behind COUNTED vmcnt waits: two stages (<= 96 KiB) in flight per CU at any time;
+//   * the stream of K steps runs ACROSS descriptors: while the last steps of a list are multiplied the first stages of the
+//     workgroup's next list are already on their way (a 12-step list would otherwise pay a pipeline fill per list).  The
+//     next lists' query-row ids (gq) ride the same queue: one 1-KiB LDS-DMA per descriptor, three descriptors ahead (a
+//     descriptor can be a single K step: its ids must have landed AND passed a barrier before the issue side reads them);
+//   * score stores stay in flight across K steps: the waits count them (they are younger than the loads they follow).
+// Same MFMA instruction, K order and (score, row) semantics as above: scores are bit-identical (the IVF tests pass on it).
+// MEASURED (same box, rocprofv3 kernel trace, tools/ivf_split.sh): C5 share 625 k rows: list scan 340 us (above) vs 384-394 us
+// (this), probe scan over the 4 096 centroids 110 vs 128 us; whole corpus 5 M rows: 2.47 vs 2.34-2.44 ms (2.37 with
+// non-temporal corpus loads, which cost the probe scan 20 us).  Fewer K steps, fewer bytes and twice the bytes in flight buy
+// nothing: the stream is bound by the per-CU request path at the rate the guide gives for HBM-sourced LDS-DMA (23-24 GB/s per
+// CU, MI355X_MICROARCH.md "Indexed rows"), not by round trips, and one 8-wave workgroup per CU has no second workgroup to
+// cover its per-descriptor seams.  Kept as a record; the shipped scan is the kernel above.
+constexpr int R_TR = 256;                           // corpus rows per tile
+constexpr int R_THR = 512;                          // 8 waves: wave (wm = w >> 1, wn = w & 1) owns rows wm*64.., queries wn*64..
+constexpr int R_A_BYTES = R_TR * SK * 2;            // 32 KiB
+constexpr int R_B_BYTES = ST * SK * 2;              // 16 KiB
+constexpr int R_STAGE = R_A_BYTES + R_B_BYTES;      // 48 KiB
+constexpr int R_NS = 3;
+#ifndef MRAG_IVFS_A_AUX
+#define MRAG_IVFS_A_AUX 0
+#endif
+constexpr int R_A_AUX = MRAG_IVFS_A_AUX;            // cache policy of the corpus-row loads (2 = non-temporal)
+constexpr int R_GQ = 4;                             // ring of query-row id blocks: the descriptor being staged and the three after it
+constexpr int R_GQ_OFF = R_NS * R_STAGE;            // int64 [R_GQ][128]
+constexpr int R_DS_OFF = R_GQ_OFF + R_GQ * ST * 8;  // int [R_GQ][IVFS_DESC_WORDS]: the descriptors' words, passed from the issue side to the compute side
+constexpr int R_LDS = R_DS_OFF + R_GQ * IVFS_DESC_WORDS * 4;   // 151 680 B
+
+__device__ __forceinline__ void r_wait_vm(int n) {   // s_waitcnt vmcnt(<= n): the immediate must be a constant
+  if (n >= 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+  else if (n >= 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+  else if (n >= 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+struct RDesc {                 // one descriptor's scalars (common.h: IVFS_DESC_WORDS)
+  int gq_base, nq, n_rows, r_off, pitch, n_tiles;
+  int64_t row0, soff;
+};
+
+template <int DT>
+__global__ __launch_bounds__(R_THR) void ivfs_scan256_kernel(const uint16_t* __restrict__ corpus, const uint16_t* __restrict__ queries,
+                                                             int ld, int64_t zero_row, const int* __restrict__ desc, int n_desc,
+                                                             const int* __restrict__ n_desc_dev, const int64_t* __restrict__ gq,
+                                                             float* __restrict__ S) {
+  typedef typename SMfma<DT>::frag frag;
+  extern __shared__ __attribute__((aligned(16))) char rsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int n_real = n_desc_dev ? *n_desc_dev : n_desc;
+  // blocks go to XCDs round-robin: XCD x owns the contiguous run [x * per, (x + 1) * per) of descriptors (a list's
+  // workgroups are neighbours: one L2 fetches it); this workgroup takes every (gridDim / 8)-th of them
+  const int per = (n_real + 7) >> 3;
+  const int it0 = (int)(blockIdx.x >> 3), it_step = (int)(gridDim.x >> 3);
+  const int xbase = (int)(blockIdx.x & 7) * per;
+  auto lin_of = [&](int ord) -> int {                  // ord-th descriptor of this workgroup, or -1
+    const int it = it0 + ord * it_step;
+    if (it >= per) return -1;
+    const int lin = xbase + it;
+    return lin < n_real ? lin : -1;
+  };
+  int* ds_lds = (int*)(rsm + R_DS_OFF);
+  auto load_desc = [&](const int* d) -> RDesc {
+    RDesc r;
+    r.gq_base = d[0]; r.nq = d[1]; r.n_rows = d[3]; r.r_off = d[4]; r.pitch = d[7];
+    r.row0 = (int64_t)(uint32_t)d[2];
+    r.soff = (int64_t)(uint32_t)d[5] | ((int64_t)d[6] << 32);
+    r.n_tiles = (r.n_rows + R_TR - 1) / R_TR;
+    return r;
+  };
+  const int nk = ld / SK;
+  const uint32_t row_b = (uint32_t)ld * 2u;
+  int64_t* gq_lds = (int64_t*)(rsm + R_GQ_OFF);
+
+  // per-lane parts of the LDS-DMA sources.  A: wave w fills the 1-KiB chunks 4w..4w+3 (8 rows x 128 B) of the corpus tile,
+  // B: chunks 2w, 2w+1 of the query block; the 16-byte piece a lane fetches is XOR-swizzled by its row (conflict-free reads)
+  uint32_t a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (4 * w + i) * 8 + (lane >> 3);
+    a_off[i] = (uint32_t)r * row_b + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+  }
+  int b_row[2];
+  uint32_t b_kc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    b_row[i] = (2 * w + i) * 8 + (lane >> 3);
+    b_kc[i] = (uint32_t)(((lane & 7) ^ ((b_row[i] >> 1) & 7)) * 16);
+  }
+  // one LDS-DMA (wave 0, 1 KiB) brings the 128 query-row ids of descriptor `lin` into gq slot `slot`; returns ops issued
+  auto issue_gq = [&](int lin, int slot) -> int {
+    if (lin < 0 || w != 0) return 0;
+    const int gb = desc[(size_t)lin * IVFS_DESC_WORDS];
+    if (gb < 0) return 0;                                             // identity map: no ids to fetch
+    __builtin_amdgcn_global_load_lds((s_glb_vptr)((const char*)(gq + gb) + lane * 16), (s_lds_vptr)(rsm + R_GQ_OFF + slot * (ST * 8)), 16, 0, 0);
+    return 1;
+  };
+
+  // ---- issue side: cursor over (descriptor, tile, k step) of the NEXT stage to issue ------------------------------
+  int i_ord = 0, i_lin = lin_of(0), i_tile = 0, i_kk = 0, i_buf = 0;
+  RDesc id{};
+  const char* i_bptr[2] = {nullptr, nullptr};                        // this lane's two query-row sources of the issue descriptor
+  auto issue_enter = [&]() {                                          // the issue cursor has just moved to descriptor i_ord (i_lin >= 0)
+    const int* dg = desc + (size_t)i_lin * IVFS_DESC_WORDS;
+    id = load_desc(dg);
+    // the compute side reaches this descriptor at least one barrier later: it takes the words from LDS instead of waiting
+    // out a global (scalar) load with all eight waves idle
+    if (tid < IVFS_DESC_WORDS) ds_lds[(i_ord % R_GQ) * IVFS_DESC_WORDS + tid] = dg[tid];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t qrow;
+      if (id.gq_base < 0) qrow = (int64_t)(-1 - id.gq_base) + b_row[i];
+      else { qrow = b_row[i] < id.nq ? gq_lds[(i_ord % R_GQ) * ST + b_row[i]] : -1; if (qrow < 0) qrow = zero_row; }
+      i_bptr[i] = (const char*)queries + (size_t)qrow * row_b + b_kc[i];
+    }
+  };
+  // issue the next stage of the stream (if any); returns this wave's number of VMEM ops
+  auto issue_next = [&]() -> int {
+    if (i_lin < 0) return 0;
+    int ops = 0;
+    if (i_tile == 0 && i_kk == 0) ops += issue_gq(lin_of(i_ord + 3), (i_ord + 3) % R_GQ);   // ids of the third descriptor from here
+    char* la = rsm + i_buf * R_STAGE;
+    const char* abase = (const char*)corpus + (size_t)(id.row0 + (int64_t)i_tile * R_TR) * row_b + (size_t)i_kk * (SK * 2);
+    const int rows_left = id.n_rows - i_tile * R_TR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((4 * w + i) * 8 < rows_left) {
+        __builtin_amdgcn_global_load_lds((s_glb_vptr)(abase + a_off[i]), (s_lds_vptr)(la + (4 * w + i) * 1024), 16, 0, R_A_AUX);
+        ++ops;
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if ((2 * w + i) * 8 < id.nq) {
+        __builtin_amdgcn_global_load_lds((s_glb_vptr)(i_bptr[i] + (size_t)i_kk * (SK * 2)), (s_lds_vptr)(la + R_A_BYTES + (2 * w + i) * 1024), 16, 0, 0);
+        ++ops;
+      }
+    if (++i_buf == R_NS) i_buf = 0;
+    if (++i_kk == nk) {
+      i_kk = 0;
+      if (++i_tile == id.n_tiles) {
+        i_tile = 0;
+        ++i_ord;
+        i_lin = lin_of(i_ord);
+        if (i_lin >= 0) issue_enter();
+      }
+    }
+    return ops;
+  };
+
+  // ---- prologue: query-row ids of the first three descriptors, then two stages in flight -----------------------------
+  // (ids of descriptor X are issued with the first stage of X - 3 and read when the issue side enters X, i.e. while it
+  // issues the last stage of X - 1: at least three stages, hence one wait + barrier of the issuing wave, later.  The
+  // barriers between the prologue's issue calls keep a slot's readers ahead of its next writer.)
+  if (i_lin < 0) return;
+  issue_gq(i_lin, 0);
+  issue_gq(lin_of(1), 1);
+  issue_gq(lin_of(2), 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  issue_enter();
+  const RDesc first_desc = id;      // (the compute side starts on descriptor 0; the prologue's issues below may already move `id` on)
+  __syncthreads();
+  // ops of the stages issued but not yet waited for and the stores issued behind each of them
+  issue_next();                     // stage s     (the one the first step needs; its op count is never waited on alone)
+  __syncthreads();
+  int ops2 = issue_next();          // stage s + 1
+  int st1 = 0, st2 = 0;             // score stores issued after stage s / after stage s + 1 (younger than them)
+
+  // ---- compute side ------------------------------------------------------------------------------------------------
+  int c_ord = 0, c_tile = 0, c_kk = 0, c_buf = 0;
+  RDesc cd = first_desc;
+  const int frow = lane & 15, fsw = frow >> 1;
+  const int a_rd = (wm * 64 + frow) * 128, b_rd = R_A_BYTES + (wn * 64 + frow) * 128;
+  const int ph0 = ((lane >> 4) ^ fsw) * 16;
+  s_f32x4 acc[4][4];
+  while (true) {
+    // stage s has landed once everything older than {stores after s, stage s + 1, stores after s + 1} is done
+    r_wait_vm(st1 + ops2 + st2);
+    __builtin_amdgcn_s_barrier();          // everyone's pieces of stage s are in LDS; everyone is done with stage s - 1's buffer
+    asm volatile("" ::: "memory");
+    const int ops3 = issue_next();         // stage s + 2 goes into the buffer stage s - 1 occupied
+    int st3 = 0;
+    const char* sb = rsm + c_buf * R_STAGE;
+    if (c_kk == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (s_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // this wave's 64 x 64 piece: only the 16-row / 16-query fragments that hold real rows / queries (wave-uniform tests)
+    const int ni = min(4, (cd.n_rows - c_tile * R_TR - wm * 64 + 15) >> 4);
+    const int nj = min(4, (cd.nq - wn * 64 + 15) >> 4);
+    if (ni > 0 && nj > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ph = ks ? (ph0 ^ 64) : ph0;
+        frag af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < ni) af[i] = *(const frag*)(sb + a_rd + i * 2048 + ph);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nj) bf[j] = *(const frag*)(sb + b_rd + j * 2048 + ph);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < ni && j < nj) acc[i][j] = SMfma<DT>::run(af[i], bf[j], acc[i][j]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the buffer are done before it reaches the next barrier
+    if (++c_buf == R_NS) c_buf = 0;
+    bool done = false;
+    if (++c_kk == nk) {
+      // scores of this tile: lane holds rows r0..r0+3 (consecutive) of query slot q per accumulator
+      const int rl = c_tile * R_TR + wm * 64 + (lane >> 4) * 4;
+      const int rows4 = (cd.n_rows + 3) & ~3;
+      float* Sb = S + cd.soff;
+      if (ni > 0 && nj > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j >= nj) continue;                                   // (wave-uniform: no store instruction is issued)
+          const int q = wn * 64 + j * 16 + (lane & 15);
+          float* sq = Sb + (size_t)q * cd.pitch + cd.r_off;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i >= ni) continue;
+            const int r0 = rl + i * 16;
+            if (q < cd.nq && r0 < rows4) *(s_f32x4*)(sq + r0) = acc[i][j];
+            ++st3;                                                 // one VMEM op per (i, j) the wave executes
+          }
+        }
+      }
+      c_kk = 0;
+      if (++c_tile == cd.n_tiles) {
+        c_tile = 0;
+        ++c_ord;
+        const int nl = lin_of(c_ord);
+        if (nl < 0) done = true; else cd = load_desc(ds_lds + (c_ord % R_GQ) * IVFS_DESC_WORDS);
+      }
+    }
+    if (done) break;
+    ops2 = ops3; st1 = st2; st2 = st3;
+  }
+}
+
+#endif  // MRAG_IVFS_SCAN256
+
 // ------------------------------------------------------------------ per-query selection
 constexpr int SEL_THR = 256;
 constexpr int SEL_EPT = 32;                        // candidate scores a thread keeps in registers
@@ -313,9 +578,68 @@ __device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
     if (DENSE && p.count_out && p.row_weight[row] > 0) atomicAdd(&p.count_out[row], 1);
   };
   const int kk = total < k ? total : k;
-  bool serial = total > SEL_CAP || total <= k;     // (fewer candidates than k: all of them, in order -- the serial path does that)
+  bool serial = total <= k;                        // (fewer candidates than k: all of them, in order -- the serial path does that)
+  const bool streamed = !serial && total > SEL_CAP;   // more candidates than the register path holds: two streaming passes
 
-  if (!serial) {
+  // k-th largest of the 256 thread maxima: the largest P with #(tmax >= P) >= k, two bits per step
+  // (four bits per step -- 15 ballots, half the barriers -- was slower: the 64-bit unpacking of 15 counts outweighs them)
+  auto kth_of_thread_maxima = [&](uint32_t tmax) -> uint32_t {
+    uint32_t P = 0u;
+    for (int bit = 30; bit >= 0; bit -= 2) {
+      const uint32_t c1 = P | (1u << bit), c2 = P | (2u << bit), c3 = P | (3u << bit);
+      const unsigned long long n1 = __popcll(__ballot(tmax >= c1)), n2 = __popcll(__ballot(tmax >= c2)), n3 = __popcll(__ballot(tmax >= c3));
+      if (lane == 0) red[red_slot][w] = n1 | (n2 << 16) | (n3 << 32);
+      __syncthreads();
+      unsigned long long t = 0;
+      for (int i = 0; i < SEL_THR / 64; ++i) t += red[red_slot][i];
+      red_slot ^= 1;
+      const int N1 = (int)(t & 0xFFFF), N2 = (int)((t >> 16) & 0xFFFF), N3 = (int)((t >> 32) & 0xFFFF);
+      P = N3 >= k ? c3 : N2 >= k ? c2 : N1 >= k ? c1 : P;
+    }
+    return P;
+  };
+  // wave-aggregated shortlist append: one LDS atomic per wave and call that has any hit (a lane-by-lane atomicAdd on the one
+  // counter serialises ~k lanes); call with the whole wave converged
+  auto shortlist_append = [&](bool hit, uint32_t key, int e) {
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&n_cand, (int)__popcll(hm));
+      base = __shfl(base, 0);
+      const int c = base + (int)__popcll(hm & ((1ull << lane) - 1ull));
+      if (hit && c < SEL_CAND) { cand_key[c] = key; cand_e[c] = (uint32_t)e; }
+    }
+  };
+  // the shortlisted entries get their original rows, are ranked by counting on (score desc, row asc); ranks < k are the answer
+  auto rank_shortlist = [&]() -> bool {
+    __syncthreads();
+    const int nc = n_cand;
+    if (nc > SEL_CAND) return false;               // (workgroup-uniform) degenerate ties: the serial path
+    for (int c = tid; c < nc; c += SEL_THR) {
+      const int e = (int)cand_e[c];
+      int j = 0;
+      if (!DENSE) {                                // segment of entry e: binary search over the prefix sums
+        int lo = 0, hi = np;                       // seg_pre[lo] <= e < seg_pre[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_pre[mid] <= e) lo = mid; else hi = mid; }
+        j = lo;
+      }
+      cand_row[c] = row_at(j, e - seg_pre[j]);
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += SEL_THR) {
+      const uint32_t mk = cand_key[c];
+      const int64_t mr = cand_row[c];
+      int rank = 0;
+      for (int i = 0; i < nc; ++i) {
+        const uint32_t ok = cand_key[i];
+        rank += (ok > mk || (ok == mk && cand_row[i] < mr)) ? 1 : 0;
+      }
+      if (rank < k) emit(rank, mk, mr);
+    }
+    return true;
+  };
+
+  if (!serial && !streamed) {
     // ---- fast path: scores -> registers
     uint32_t kr[SEL_EPT];
     uint32_t tmax = 0u;
@@ -340,62 +664,40 @@ __device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
         tmax = key > tmax ? key : tmax;
       }
     }
-    // k-th largest of the 256 thread maxima: the largest P with #(tmax >= P) >= k, two bits per step
-    // (four bits per step -- 15 ballots, half the barriers -- was slower: the 64-bit unpacking of 15 counts outweighs them)
-    uint32_t P = 0u;
-    for (int bit = 30; bit >= 0; bit -= 2) {
-      const uint32_t c1 = P | (1u << bit), c2 = P | (2u << bit), c3 = P | (3u << bit);
-      const unsigned long long n1 = __popcll(__ballot(tmax >= c1)), n2 = __popcll(__ballot(tmax >= c2)), n3 = __popcll(__ballot(tmax >= c3));
-      if (lane == 0) red[red_slot][w] = n1 | (n2 << 16) | (n3 << 32);
-      __syncthreads();
-      unsigned long long t = 0;
-      for (int i = 0; i < SEL_THR / 64; ++i) t += red[red_slot][i];
-      red_slot ^= 1;
-      const int N1 = (int)(t & 0xFFFF), N2 = (int)((t >> 16) & 0xFFFF), N3 = (int)((t >> 32) & 0xFFFF);
-      P = N3 >= k ? c3 : N2 >= k ? c2 : N1 >= k ? c1 : P;
-    }
-    // shortlist
-    // (wave-aggregated append: one LDS atomic per wave and register slot that has any hit -- a lane-by-lane atomicAdd on the
-    // one counter serialises ~k lanes)
+    const uint32_t P = kth_of_thread_maxima(tmax);
 #pragma unroll
     for (int i = 0; i < SEL_EPT; ++i) {
       const int e = tid + i * SEL_THR;
-      const bool hit = e < total && kr[i] >= P;
-      const unsigned long long hm = __ballot(hit);
-      if (hm) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&n_cand, (int)__popcll(hm));
-        base = __shfl(base, 0);
-        const int c = base + (int)__popcll(hm & ((1ull << lane) - 1ull));
-        if (hit && c < SEL_CAND) { cand_key[c] = kr[i]; cand_e[c] = (uint32_t)e; }
+      shortlist_append(e < total && kr[i] >= P, kr[i], e);
+    }
+    if (!rank_shortlist()) serial = true;
+  }
+  if (streamed) {
+    // ---- more than 8192 candidates (long lists: C5's whole 5 M rows on one GPU give ~39 000 per query): the same
+    // selection with the scores streamed twice instead of held in registers.  Pass 1: every thread's maximum over its
+    // entries (segment by segment, entry t of a segment on thread t mod 256: coalesced, 8 loads in flight) -> the k-th
+    // largest thread maximum P, a lower bound of the k-th best score.  Pass 2: the entries >= P are the shortlist.
+    uint32_t tmax = 0u;
+    for (int j = 0; j < np; ++j) {
+      const float* sp = seg_ptr[j];
+      const int cnt = seg_cnt[j];
+#pragma unroll 8
+      for (int t = tid; t < cnt; t += SEL_THR) {
+        const uint32_t key = s_f32_ord(sp[t]);
+        tmax = key > tmax ? key : tmax;
       }
     }
-    __syncthreads();
-    const int nc = n_cand;
-    if (nc > SEL_CAND) serial = true;              // (workgroup-uniform)
-    else {
-      for (int c = tid; c < nc; c += SEL_THR) {
-        const int e = (int)cand_e[c];
-        int j = 0;
-        if (!DENSE) {                              // segment of entry e: binary search over the prefix sums
-          int lo = 0, hi = np;                     // seg_pre[lo] <= e < seg_pre[hi]
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_pre[mid] <= e) lo = mid; else hi = mid; }
-          j = lo;
-        }
-        cand_row[c] = row_at(j, e - seg_pre[j]);
-      }
-      __syncthreads();
-      for (int c = tid; c < nc; c += SEL_THR) {
-        const uint32_t mk = cand_key[c];
-        const int64_t mr = cand_row[c];
-        int rank = 0;
-        for (int i = 0; i < nc; ++i) {
-          const uint32_t ok = cand_key[i];
-          rank += (ok > mk || (ok == mk && cand_row[i] < mr)) ? 1 : 0;
-        }
-        if (rank < k) emit(rank, mk, mr);
+    const uint32_t P = kth_of_thread_maxima(tmax);
+    for (int j = 0; j < np; ++j) {
+      const float* sp = seg_ptr[j];
+      const int cnt = seg_cnt[j], pre = seg_pre[j];
+      for (int t0 = 0; t0 < cnt; t0 += SEL_THR) {          // (uniform trip count: the append's ballot needs the wave converged)
+        const int t = t0 + tid;
+        const uint32_t key = t < cnt ? s_f32_ord(sp[t]) : 0u;
+        shortlist_append(t < cnt && key >= P, key, pre + t);
       }
     }
+    if (!rank_shortlist()) serial = true;
   }
   if (serial) {
     // ---- serial path: kk rounds of arg-max in (score desc, row asc) order, strictly after the previous winner
@@ -468,6 +770,20 @@ int ivfs_scan(const uint16_t* corpus, const uint16_t* queries, int ld, int dtype
   if (ld % SK) return fail(MRAG_ERR_INVALID, "ivfs_scan: ld %d is not a multiple of %d", ld, SK);
   static int cus = 0;
   if (!cus) { hipDeviceProp_t pr; int dev = 0; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+#ifdef MRAG_IVFS_SCAN256
+  // experiment build only: MRAG_IVFS_SCAN=256 selects the 256-row / ring-of-three form (see its header for the numbers)
+  static const bool scan256 = [] { const char* e = getenv("MRAG_IVFS_SCAN"); return e && atoi(e) == 256; }();
+  if (scan256 && !dbg) {
+    typedef void (*Fn)(const uint16_t*, const uint16_t*, int, int64_t, const int*, int, const int*, const int64_t*, float*);
+    const Fn fn = dtype == MRAG_F16 ? (Fn)ivfs_scan256_kernel<MRAG_F16> : (Fn)ivfs_scan256_kernel<MRAG_BF16>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[dtype == MRAG_F16]) { MRAG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS)); attr_done[dtype == MRAG_F16] = true; }
+    const unsigned grid256 = (unsigned)std::min<int64_t>((int64_t)(n_desc + 7) / 8 * 8, (int64_t)cus / 8 * 8);   // one workgroup per CU
+    hipLaunchKernelGGL(fn, dim3(grid256), dim3(R_THR), R_LDS, stream, corpus, queries, ld, zero_row, desc, n_desc, n_desc_dev, gq, S);
+    MRAG_HIP(hipGetLastError());
+    return MRAG_OK;
+  }
+#endif
   static const int wg_per_cu = [] { const char* e = getenv("MRAG_IVFS_WG_PER_CU"); return e ? atoi(e) : 2; }();
   const unsigned grid = wg_per_cu > 0 ? (unsigned)std::min<int64_t>((int64_t)(n_desc + 7) / 8 * 8, (int64_t)cus * wg_per_cu / 8 * 8)
                                       : (unsigned)((n_desc + 7) / 8 * 8);      // (0: one workgroup per descriptor)

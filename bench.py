@@ -352,7 +352,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    gemm_ms, step_ms = [], []
+    gemm_ms, step_ms, phase_ms = [], [], []
     fence()
     t0 = time.perf_counter()
     t_prev = t0
@@ -362,6 +362,7 @@ def main():
         step_ms.append((t_now - t_prev) * 1e3)
         t_prev = t_now
         gemm_ms.append(sh.index.last_timing_ms()[0])
+        phase_ms.append(dict(sh.last_phases))            # (CUDA events recorded during the step, read after its one sync)
     fence()
     elapsed = time.perf_counter() - t0
     sc, ids = sc.copy(), ids.copy()
@@ -416,6 +417,22 @@ def main():
         tmax = torch.tensor([elapsed_h2d_pipe], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed_h2d_pipe = float(tmax.item())
+
+    # N > 1: the same steps with the batch cut in two halves, the all-gather of half A in flight under the local search of half B
+    elapsed_pipe, pipe_phase_ms = None, []
+    if world > 1:
+        for _ in range(2):
+            sh.search(queries, k, pipeline=True)
+        fence()
+        t3 = time.perf_counter()
+        for _ in range(n_h2d):
+            sh.search(queries, k, pipeline=True)
+            pipe_phase_ms.append(dict(sh.last_phases))
+        fence()
+        elapsed_pipe = time.perf_counter() - t3
+        tmax = torch.tensor([elapsed_pipe], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed_pipe = float(tmax.item())
 
     # held clock under K2: one more step with the in-kernel stamps on
     clock_ghz = None
@@ -476,7 +493,17 @@ def main():
                          "timing": f"hipEvents around the launch, mean over the {args.steps} timed steps"},
             "cpu_baseline": None,
             "recall_at_10": None,
+            # rank 0's per-phase device ms of a step (median over the timed steps): local search (K1 + K2 + K4), pack,
+            # all-gather, unpack + merge, result D2H -- the Amdahl terms of SURVEY 8e next to the one number above
+            "step_phases_ms": {kk_: float(np.median([p_.get(kk_, 0.0) for p_ in phase_ms])) for kk_ in
+                               ("local_ms", "pack_ms", "gather_ms", "merge_ms", "d2h_ms")},
         }
+        if elapsed_pipe is not None:
+            out["two_half_pipeline"] = {"ms_per_step": elapsed_pipe / n_h2d * 1e3, "value": nq * n_h2d / elapsed_pipe,
+                                        "phases_ms": {kk_: float(np.median([p_.get(kk_, 0.0) for p_ in pipe_phase_ms])) for kk_ in
+                                                      ("local_ms", "pack_ms", "gather_ms", "merge_ms", "d2h_ms")},
+                                        "note": "batch cut in two halves, all-gather of half A (async_op) under the local search of half B; "
+                                                "gather_ms = the part of the collectives the local search did not cover; `value` above is the one-shot step"}
         on_ms = float(np.median(online_ms))
         on_bytes = (sh.hi - sh.lo) * d * 2.0 + d * 2.0
         out["online_roofline"] = {"bound": "hbm", "kernel": "bf_stream_topk_kernel", "workload": "1 query x this rank's rows, k=10",

@@ -203,6 +203,11 @@ def test_rccl_exchange_path_single_rank():
         for mode in ("device", "host"):
             s_, i_ = sh.search(q, k, merge=mode, force_collective=True)
             assert (i_ == ref_i).all() and np.array_equal(s_, ref_s), mode
+            assert {"local_ms", "pack_ms", "gather_ms", "d2h_ms"} <= set(sh.last_phases), sh.last_phases
+            # two-half pipeline (all-gather of half A async on RCCL's stream under the local search of half B) == one shot
+            s_, i_ = sh.search(q, k, merge=mode, force_collective=True, pipeline=True)
+            assert (i_ == ref_i).all() and np.array_equal(s_, ref_s), (mode, "pipeline")
+            assert sh.last_phases["local_ms"] > 0
     finally:
         if created:
             dist.destroy_process_group()

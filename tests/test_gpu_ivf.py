@@ -100,7 +100,8 @@ def _ivf_with(c16, cen):
 def test_select_ties_and_large_candidate_sets():
     """The score-segment regime's per-query selection (csrc/ivf_scan.hip): order is (score desc, original row asc) also
     when hundreds of rows tie on the k-th score (shortlist overflow -> serial path) and when a query has more
-    candidates than the register-resident fast path holds (> 8192 -> serial path)."""
+    candidates than the register-resident fast path holds (> 8192 -> the two-pass streamed path; with > 512 ties on the
+    k-th score in it -> serial path)."""
     d, nlist = 64, 8
     rng = np.random.default_rng(5)
     base = ds.normalize_round(ds.make_gaussian(3000, d, 21))
@@ -132,6 +133,21 @@ def test_select_ties_and_large_candidate_sets():
     np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
     strict, bad = ds.gap_aware_id_match(ids, sc, ri, rv, tol=1e-5)
     assert bad == 0
+    # the streamed path with exact ties: 40 copies of three rows (ranked inside the shortlist, lowest original rows first)
+    # and 900 copies of a fourth (more ties than the shortlist holds -> serial path), k below / across / above the copies
+    tied = np.concatenate([big, np.repeat(big[:3], 40, axis=0), np.repeat(big[3:4], 900, axis=0)], axis=0)
+    tied = tied[rng.permutation(len(tied))]
+    ix6 = _ivf_with(tied, cen5)
+    q6 = np.concatenate([big[:4], qs[:4]], axis=0)
+    for k in (5, 41, 64):
+        sc, ids = ix6.search(q6, k, 4, normalize=False)
+        rv, ri = ds.ivf_search(q6, tied, cen5, ix6.assignments().astype(np.int64), 4, k)
+        np.testing.assert_allclose(sc, rv, rtol=0, atol=1e-5)
+        for qi in range(4):
+            copies = np.sort(np.nonzero((tied == q6[qi]).all(axis=1))[0])
+            m = min(k, len(copies))
+            assert (ids[qi][:m] == copies[:m]).all(), (k, qi, ids[qi][:6], copies[:6])
+        assert ds.gap_aware_id_match(ids[4:], sc[4:], ri[4:], rv[4:], tol=1e-5)[1] == 0
 
 
 def test_fused_regime_gives_the_same_answer():
