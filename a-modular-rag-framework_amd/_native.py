@@ -58,6 +58,7 @@ SIGNATURES = {
     "mrag_index_dim": [_h, C.POINTER(_i)],
     "mrag_index_set_id_base": [_h, _i64],
     "mrag_index_max_k": [_i64, C.POINTER(_i)],
+    "mrag_index_last_wide_redone": [C.POINTER(_i64)],
     "mrag_index_get_rows": [_h, _i64, _i64, _vp, _i, _vp],
     "mrag_index_search": [_h, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mrag_index_score_rows": [_h, _vp, _i, _i, _vp, _i64, _vp, _vp],

@@ -1643,6 +1643,32 @@ __global__ __launch_bounds__(256) void score_rows_kernel(const uint16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Wide batches (64 < k <= 256, more than a handful of queries -- batch evaluation with the reference's 200-candidate pool,
+// config/settings.yaml:101-102): the batch kernel keeps at most KMAX = 64 entries per (query, corpus split), so it runs
+// with k' = 64 over S >= 4k / 64 splits and the merge takes the k best of the S x 64 candidates.  That answer is exact
+// unless some split held MORE than 64 of the query's true top k; this kernel checks it: a split whose list is full and
+// whose worst kept entry still beats the merged k-th entry may have dropped rows that belong in the answer.  Flagged
+// queries (a handful per 10 000 on i.i.d. rows; many when a query's neighbours sit in adjacent rows) are redone exactly
+// by the streaming kernel.  One thread per query.
+__global__ void bf_wide_verify_kernel(const uint2* __restrict__ list, const int* __restrict__ counts, int S, int k_kept, int k,
+                                      int64_t nq, const float* __restrict__ out_scores, const int64_t* __restrict__ out_ids,
+                                      int64_t id_base, int* __restrict__ need) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int t = (int)(q / TQ), ql = (int)(q % TQ);
+  const int64_t tid_ = out_ids[q * k + k - 1];
+  const uint64_t key_tau = tid_ < 0 ? 0ull : make_key(__float_as_uint(out_scores[q * k + k - 1]), (uint32_t)(tid_ - id_base));
+  int bad = 0;
+  for (int s = 0; s < S; ++s) {
+    const size_t wq = (size_t)(t * S + s) * TQ + ql;
+    if (counts[wq] >= k_kept) {
+      const uint2 e = list[wq * QCAP + (k_kept - 1)];
+      if (make_key(e.x, e.y) > key_tau) bad = 1;
+    }
+  }
+  need[q] = bad;
+}
+
 struct BfIndex : Object {
   int dim = 0, ld = 0, metric = 0, dtype = MRAG_F16;
   int64_t n = 0, cap_rows = 0, id_base = 0;
@@ -1722,6 +1748,8 @@ static void choose_split(int T, int n_ctiles, int* S_out, int* xcd_out) {
 }
 
 
+static int64_t g_wide_redone = 0;   // queries the last wide-batch search redid through the streaming kernel (tests / tools)
+int64_t bf_last_wide_redone() { return g_wide_redone; }
 int bf_max_k() { return KMAX; }            // fused batch kernel / IVF list scan
 int bf_max_k_wide() { return KMAX_WIDE; }  // streaming kernel, 8 queries per launch
 int64_t bf_round_rows(int64_t n) { return round_up(n, TM); }
@@ -1800,10 +1828,11 @@ int bf_launch(const BfLaunch& a) {
     return MRAG_OK;
   }
   const int n_ctiles = (int)((a.n_rows + TM - 1) / TM);
-  if (a.k > KMAX || (a.nq <= (a.k > 32 ? 8 : SQ) && n_ctiles >= 8)) {
-    // ---- online regime: HBM-bound streaming kernel (K2s), one workgroup per CU-sized corpus split ----
-    // k <= 64: up to 16 queries per launch; 64 < k <= 256: 8 per launch with 512-entry lists, any nq
-    // (larger batches run as consecutive 8-query launches: exact, HBM-bound per launch, not the batch kernel)
+  // ---- online regime: HBM-bound streaming kernel (K2s), one workgroup per CU-sized corpus split ----
+  // k <= 64: up to 16 queries per launch; 64 < k <= 256: 8 per launch with 512-entry lists, any number of queries as
+  // consecutive launches (exact, one HBM pass each).  `extra_counts`: ints the caller keeps behind the per-region counts.
+  auto run_stream = [&](const uint16_t* queries, int64_t nq_s, float* out_scores, int64_t* out_ids, bool record_end,
+                        size_t extra_counts) -> int {
     typedef void (*SFn)(StreamParams);
     static const SFn sfns[2][2] = {{bf_stream_topk_kernel<MRAG_F16, 2, 128>, bf_stream_topk_kernel<MRAG_F16, 1, 512>},
                                    {bf_stream_topk_kernel<MRAG_BF16, 2, 128>, bf_stream_topk_kernel<MRAG_BF16, 1, 512>}};
@@ -1818,22 +1847,24 @@ int bf_launch(const BfLaunch& a) {
       s_attr[di][wi] = true;
     }
     const int S = std::max(1, std::min(n_ctiles, 256));
-    MRAG_TRY(a.lists->ensure((size_t)S * TQ * QCAP * 8));
-    MRAG_TRY(a.counts->ensure(((size_t)S * TQ + 16) * sizeof(int)));   // + the K4s fallback flags of one query group
-    for (int64_t g0 = 0; g0 < a.nq; g0 += grp) {
-      const int64_t gq = std::min<int64_t>(grp, a.nq - g0);
+    if (!extra_counts) {    // (a caller with extra_counts has sized both workspaces itself: ensure() does not keep contents)
+      MRAG_TRY(a.lists->ensure((size_t)S * TQ * QCAP * 8));
+      MRAG_TRY(a.counts->ensure(((size_t)S * TQ + 16) * sizeof(int)));   // + the K4s fallback flags of one query group
+    }
+    for (int64_t g0 = 0; g0 < nq_s; g0 += grp) {
+      const int64_t gq = std::min<int64_t>(grp, nq_s - g0);
       StreamParams sp;
-      sp.corpus = a.corpus; sp.queries = a.queries + (size_t)g0 * a.ld; sp.ld = a.ld; sp.ksteps = a.ld / BK;
+      sp.corpus = a.corpus; sp.queries = queries + (size_t)g0 * a.ld; sp.ld = a.ld; sp.ksteps = a.ld / BK;
       sp.n_rows = (int)a.n_rows; sp.n_ctiles = n_ctiles; sp.nq = (int)gq; sp.S = S; sp.k = a.k;
       sp.list = (uint2*)a.lists->p; sp.counts = (int*)a.counts->p;
       hipLaunchKernelGGL(sfns[di][wi], dim3((unsigned)S), dim3(NTHR), slds[wi], stream, sp);
       MRAG_HIP(hipGetLastError());
-      if (g0 + grp >= a.nq && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+      if (record_end && g0 + grp >= nq_s && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
       MergeParams mp;
       mp.list = sp.list; mp.counts = sp.counts;
       mp.T = 1; mp.S = S; mp.k = a.k; mp.nq = gq; mp.id_base = a.id_base;
       mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
-      mp.out_scores = a.out_scores + (size_t)g0 * a.k; mp.out_ids = a.out_ids + (size_t)g0 * a.k;
+      mp.out_scores = out_scores + (size_t)g0 * a.k; mp.out_ids = out_ids + (size_t)g0 * a.k;
       if (wi || S > 64) {
         // K4s (heads of the sorted lists through LDS) + K4w for the queries it flags (adversarial layouts only)
         static bool s_attr2 = false;
@@ -1850,6 +1881,85 @@ int bf_launch(const BfLaunch& a) {
         hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)gq), dim3(64), (size_t)mp.cap * 8, stream, mp);
       }
       MRAG_HIP(hipGetLastError());
+    }
+    return MRAG_OK;
+  };
+  static const bool wide_off = [] { const char* e = getenv("MRAG_NO_WIDE_BATCH"); return e && atoi(e) != 0; }();   // test knob: every k > 64 search through the streaming kernel
+  const bool wide_batch = a.k > KMAX && a.nq > 32 && n_ctiles >= 64 && !wide_off;
+  if (!a.wg_desc) g_wide_redone = 0;
+  if (!wide_batch && (a.k > KMAX || (a.nq <= (a.k > 32 ? 8 : SQ) && n_ctiles >= 8))) return run_stream(a.queries, a.nq, a.out_scores, a.out_ids, true, 0);
+  if (wide_batch) {
+    // ---- wide batch: the batch kernel at k' = 64 over S >= 4k/64 splits + merge to k + verification (bf_wide_verify_kernel),
+    // the flagged queries redone by the streaming kernel.  10 000 queries at the reference's pool of 200 were 1 250 streaming
+    // launches (one HBM pass each, ~0.5 s over 1M rows); now ceil(T / 16..19) batch-kernel launches.
+    int n_cu = 256;
+    { int S0, x0; choose_split(1, 1 << 30, &S0, &x0); n_cu = S0; }                       // (choose_split(1, inf) = CU count)
+    const int S_min = std::max(4, (4 * a.k + KMAX - 1) / KMAX);
+    const int T_max = std::max(1, std::min(MAX_QTILES_PER_LAUNCH, n_cu / S_min));
+    const int T_all = (int)((a.nq + TQ - 1) / TQ);
+    const int S_stream = std::max(1, std::min(n_ctiles, 256));
+    // one sizing of both workspaces for every launch below (ensure() drops contents)
+    const size_t grid_max = (size_t)std::max(n_cu, S_stream);          // T * S <= CUs for every launch below; the streaming redo uses S_stream regions
+    MRAG_TRY(a.lists->ensure(grid_max * TQ * QCAP * 8));
+    const size_t cnt_ints = grid_max * TQ + 16;
+    const size_t flag_off = cnt_ints, need_off = flag_off + (size_t)T_max * TQ;                    // ints
+    const size_t stage_off_b = round_up((int64_t)((need_off + (size_t)a.nq) * sizeof(int)), 256);     // bytes: 8 staged query rows, then results
+    const size_t res_off_b = stage_off_b + (size_t)16 * a.ld * 2;
+    MRAG_TRY(a.counts->ensure(res_off_b + (size_t)8 * a.k * 12 + 256));
+    int* need = (int*)a.counts->p + need_off;
+    static bool s_attr3 = false;
+    if (!s_attr3) {
+      MRAG_HIP(hipFuncSetAttribute((const void*)bf_merge_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MS_CAP * 8));
+      s_attr3 = true;
+    }
+    for (int t0 = 0; t0 < T_all; t0 += T_max) {
+      const int T = std::min(T_max, T_all - t0);
+      const int64_t q0 = (int64_t)t0 * TQ;
+      const int64_t nq = std::min<int64_t>(a.nq - q0, (int64_t)T * TQ);
+      int S, xcd;
+      choose_split(T, n_ctiles, &S, &xcd);
+      const size_t grid = (size_t)T * S;
+      p.queries = a.queries + (size_t)q0 * a.ld;
+      p.n_rows = (int)a.n_rows; p.n_ctiles = n_ctiles; p.nq = (int)nq;
+      p.T = T; p.S = S; p.xcd_map = xcd; p.k = KMAX;
+      p.wg_desc = nullptr;
+      p.list = (uint2*)a.lists->p;
+      p.counts = (int*)a.counts->p;
+      MRAG_TRY(launch_k2(a.dtype, grid, stream, p));
+      if (t0 + T_max >= T_all && a.ev_k2_end) MRAG_HIP(hipEventRecord(a.ev_k2_end, stream));
+      MergeParams mp;
+      mp.list = p.list; mp.counts = p.counts;
+      mp.T = T; mp.S = S; mp.k = a.k; mp.nq = nq; mp.id_base = a.id_base;
+      mp.pair_loc = nullptr; mp.nprobe = 0; mp.row_ids = nullptr;
+      mp.out_scores = a.out_scores + (size_t)q0 * a.k;
+      mp.out_ids = a.out_ids + (size_t)q0 * a.k;
+      int* flags = (int*)a.counts->p + flag_off;
+      hipLaunchKernelGGL(bf_merge_sorted_kernel, dim3((unsigned)nq), dim3(256), (size_t)MS_CAP * 8, stream, mp, flags, MS_CAP);
+      hipLaunchKernelGGL(bf_merge_wide_kernel, dim3((unsigned)nq), dim3(256), 0, stream, mp, (const int*)flags);
+      hipLaunchKernelGGL(bf_wide_verify_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, (const uint2*)p.list, (const int*)p.counts,
+                         S, KMAX, a.k, nq, (const float*)mp.out_scores, (const int64_t*)mp.out_ids, a.id_base, need + q0);
+      MRAG_HIP(hipGetLastError());
+    }
+    // the flagged queries, exactly, eight per streaming launch (their rows staged contiguously)
+    std::vector<int> h_need((size_t)a.nq);
+    MRAG_HIP(hipMemcpyAsync(h_need.data(), need, (size_t)a.nq * sizeof(int), hipMemcpyDeviceToHost, stream));
+    MRAG_HIP(hipStreamSynchronize(stream));
+    std::vector<int64_t> redo;
+    for (int64_t q = 0; q < a.nq; ++q) if (h_need[(size_t)q]) redo.push_back(q);
+    g_wide_redone = (int64_t)redo.size();
+    uint16_t* stage = (uint16_t*)((char*)a.counts->p + stage_off_b);
+    float* r_sc = (float*)((char*)a.counts->p + res_off_b);
+    int64_t* r_id = (int64_t*)((char*)a.counts->p + res_off_b + (size_t)8 * a.k * 4);
+    for (size_t g0 = 0; g0 < redo.size(); g0 += 8) {
+      const size_t m = std::min<size_t>(8, redo.size() - g0);
+      MRAG_HIP(hipMemsetAsync(stage, 0, (size_t)16 * a.ld * 2, stream));
+      for (size_t i = 0; i < m; ++i)
+        MRAG_HIP(hipMemcpyAsync(stage + i * a.ld, a.queries + (size_t)redo[g0 + i] * a.ld, (size_t)a.ld * 2, hipMemcpyDeviceToDevice, stream));
+      MRAG_TRY(run_stream(stage, (int64_t)m, r_sc, r_id, false, 1));
+      for (size_t i = 0; i < m; ++i) {
+        MRAG_HIP(hipMemcpyAsync(a.out_scores + (size_t)redo[g0 + i] * a.k, r_sc + i * a.k, (size_t)a.k * 4, hipMemcpyDeviceToDevice, stream));
+        MRAG_HIP(hipMemcpyAsync(a.out_ids + (size_t)redo[g0 + i] * a.k, r_id + i * a.k, (size_t)a.k * 8, hipMemcpyDeviceToDevice, stream));
+      }
     }
     return MRAG_OK;
   }
@@ -1989,8 +2099,14 @@ int mrag_index_set_id_base(mrag_handle h, int64_t id_base) {
 
 int mrag_index_max_k(int64_t nq, int* out_k) {
   if (!out_k) return fail(MRAG_ERR_INVALID, "out_k is NULL");
-  (void)nq;   // every batch size is served up to the wide limit (k > 64 runs 8 queries per launch)
+  (void)nq;   // every batch size is served up to the wide limit (k > 64: streaming kernel, or the wide-batch path of bf_launch)
   *out_k = KMAX_WIDE;
+  return MRAG_OK;
+}
+
+int mrag_index_last_wide_redone(int64_t* out_queries) {
+  if (!out_queries) return fail(MRAG_ERR_INVALID, "out_queries is NULL");
+  *out_queries = bf_last_wide_redone();
   return MRAG_OK;
 }
 

@@ -143,6 +143,12 @@ class DenseIndex:
         N.check(self._lib.mrag_index_max_k(int(nq), C.byref(out)))
         return out.value
 
+    def last_wide_redone(self) -> int:
+        """Queries the last 64 < k <= 256 batch search redid through the streaming kernel (``mrag_index_last_wide_redone``)."""
+        out = C.c_int64(0)
+        N.check(self._lib.mrag_index_last_wide_redone(C.byref(out)))
+        return out.value
+
     def score_rows(self, query, row_ids, normalize: Optional[bool] = None) -> np.ndarray:
         """<query, stored row i> for every listed row (``mrag_index_score_rows``): the re-ranker's
         candidate lookup by row id.  Ids outside the index score 0.0."""

@@ -92,8 +92,13 @@ int mrag_index_set_id_base(mrag_handle h, int64_t id_base);
 int mrag_index_get_rows(mrag_handle h, int64_t row0, int64_t n, float* out, int out_is_device, void* stream);
 /* largest k mrag_index_search serves for a batch of nq queries (256: the reference's dense pool is 200
  * candidates per question, config/settings.yaml:101-102 / retrieval_backend.py:218,276).  k <= 64 runs
- * the fused batch kernel; 64 < k <= 256 runs the streaming kernel 8 queries per launch (exact, HBM-bound). */
+ * the fused batch kernel; 64 < k <= 256 runs the streaming kernel 8 queries per launch (exact, HBM-bound) for up
+ * to 32 queries, and for larger batches the batch kernel at k' = 64 per corpus split + merge + an exactness check,
+ * with the few queries the check flags redone by the streaming kernel (such a search synchronises the stream once). */
 int mrag_index_max_k(int64_t nq, int* out_k);
+/* measurement hook: queries the LAST 64 < k <= 256 batch search (any index of this process) had to redo through the
+ * streaming kernel because one corpus split held more than 64 of their true top k (0 for every other kind of search). */
+int mrag_index_last_wide_redone(int64_t* out_queries);
 /* top-k of every query against every stored row.  out_scores [nq,k] fp32 descending,
  * out_ids [nq,k] int64; slots past the corpus size hold (-inf, -1).  k > mrag_index_max_k:
  * MRAG_ERR_UNSUPPORTED (never a silent clamp). */

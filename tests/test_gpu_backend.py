@@ -43,6 +43,48 @@ def test_k_above_64_matches_oracle(nq, n, d, k):
     _check_wide(ix, q16, c16, k, id_base=1000)
 
 
+@pytest.mark.parametrize("k", [100, 200, 256])
+def test_wide_batch_k_above_64(k):
+    """Batch evaluation with the reference's pool (retrieval_backend.py:218: 200 candidates) -- more than 32 queries with
+    64 < k <= 256: the batch kernel at k' = 64 per corpus split + merge + the exactness check, flagged queries redone by the
+    streaming kernel (csrc/bf_index.hip bf_wide_verify_kernel).  i.i.d. rows: (almost) nothing is flagged; then rows stored
+    cluster by cluster with k neighbours inside ONE cluster -- one split holds a query's whole top k, everything it touches is
+    flagged and redone -- and exact integer ties.  Always the oracle's answer."""
+    from mrag_amd.index import DenseIndex
+    n, nq, d = 70_000, 700, 64
+    c16 = ds.normalize_round(ds.make_gaussian(n, d, 81))
+    q16 = ds.normalize_round(ds.make_gaussian(nq, d, 82))
+    ix = DenseIndex(d)
+    ix.set_id_base(5000)
+    ix.add(c16, normalize=False)
+    _check_wide(ix, q16, c16, k, id_base=5000)
+    assert ix.last_wide_redone() <= nq // 20
+    # fewer than 33 queries keep the streaming kernel (and reset the counter)
+    _check_wide(ix, q16[:9], c16, k, id_base=5000)
+    assert ix.last_wide_redone() == 0
+    ix.close()
+    # clustered storage order: 280 clusters x 250 adjacent rows, every query sits on a cluster centre
+    rng = np.random.default_rng(83)
+    cent = rng.standard_normal((280, d)).astype(np.float32)
+    rows = (np.repeat(cent, 250, axis=0) + 0.05 * rng.standard_normal((280 * 250, d)).astype(np.float32))
+    c2 = ds.normalize_round(rows)
+    q2 = ds.normalize_round(cent[rng.integers(0, 280, size=200)] + 0.01 * rng.standard_normal((200, d)).astype(np.float32))
+    ix2 = DenseIndex(d)
+    ix2.add(c2, normalize=False)
+    _check_wide(ix2, q2, c2, k, id_base=0)
+    assert ix2.last_wide_redone() > 0          # (the check did fire: those answers came from the exact redo)
+    ix2.close()
+    # integer-valued rows, inner product: exact fp32 sums, real ties on the k-th score -> ids must equal the oracle's
+    ci = rng.integers(-2, 3, size=(66_000, d)).astype(np.float16)
+    qi = rng.integers(-2, 3, size=(40, d)).astype(np.float16)
+    ix3 = DenseIndex(d, metric="ip")
+    ix3.add(ci, normalize=False)
+    sc, ids = ix3.search(qi, k, normalize=False)
+    rv, ri = ds.brute_force_topk(qi, ci, k)
+    assert (ids == ri).all() and (sc == rv).all()
+    ix3.close()
+
+
 def test_k_above_64_ties_adversarial_and_limit():
     from mrag_amd.index import DenseIndex
     from mrag_amd._native import MragError
