@@ -28,6 +28,12 @@ CASES = {
     "minilm2": (dict(oe.SPECS["minilm-l6"], layers=2), 41, "mean", 10, 160),
     "bge1": (dict(oe.SPECS["bge-base"], layers=1), 42, "cls", 6, 272),
 }
+# round 3: the same at FULL depth -- all 6 / 12 layers of the two BASELINE models -- in a second file,
+# so that f6_encoder.npz stays byte-identical to what round 2 committed
+CASES_FULL = {
+    "minilm6": (dict(oe.SPECS["minilm-l6"]), 43, "mean", 8, 128),
+    "bge12": (dict(oe.SPECS["bge-base"]), 44, "cls", 5, 160),
+}
 
 
 def weights_sha(w):
@@ -76,8 +82,9 @@ def hf_forward(spec, w, ids, mask, pool):
 def main():
     import torch
     import transformers as tr
-    out = {"torch_version": np.array(torch.__version__), "transformers_version": np.array(tr.__version__)}
-    for name, (spec, seed, pool, B, S) in CASES.items():
+    for cases, fname in ((CASES, "f6_encoder.npz"), (CASES_FULL, "f6b_encoder_full.npz")):
+      out = {"torch_version": np.array(torch.__version__), "transformers_version": np.array(tr.__version__)}
+      for name, (spec, seed, pool, B, S) in cases.items():
         w = oe.seeded_weights(spec, seed)
         ids, mask = batch(spec, B, S, seed + 100)
         raw, emb = hf_forward(spec, w, ids, mask, pool)
@@ -85,9 +92,9 @@ def main():
                     f"{name}.emb": emb.astype(np.float32), f"{name}.seed": np.array(seed), f"{name}.pool": np.array(pool),
                     f"{name}.layers": np.array(spec["layers"]), f"{name}.weights_sha256": np.array(weights_sha(w))})
         print(name, ids.shape, "emb", emb.shape, "sha", weights_sha(w)[:16])
-    dst = Path(__file__).resolve().parent / "f6_encoder.npz"
-    np.savez_compressed(dst, **out)
-    print("wrote", dst, dst.stat().st_size, "bytes")
+      dst = Path(__file__).resolve().parent / fname
+      np.savez_compressed(dst, **out)
+      print("wrote", dst, dst.stat().st_size, "bytes")
 
 
 if __name__ == "__main__":

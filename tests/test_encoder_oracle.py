@@ -125,3 +125,20 @@ def test_f9_oracle_matches_hf_from_pretrained(golden_dir):
     sp = dict(spec.as_dict())
     for pool, key in (("mean", "mean_normalized"), ("cls", "cls_normalized")):
         np.testing.assert_allclose(oe.forward(sp, w, ids, mask, pool=pool), np.asarray(g[key]), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["minilm6", "bge12"])
+def test_f6b_oracle_matches_hf_at_full_depth(golden_dir, case):
+    """The fp64 oracle against the committed HF outputs at full depth (6 / 12 layers): the pin the GPU tests lean on."""
+    import hashlib
+    z = np.load(golden_dir / "f6b_encoder_full.npz")
+    base = {"minilm6": "minilm-l6", "bge12": "bge-base"}[case]
+    spec = dict(oe.SPECS[base])
+    w = oe.seeded_weights(spec, int(z[f"{case}.seed"]))
+    h = hashlib.sha256()
+    for k in w:
+        h.update(k.encode()); h.update(np.ascontiguousarray(w[k]).tobytes())
+    assert h.hexdigest() == str(z[f"{case}.weights_sha256"])
+    sub = slice(0, 3)
+    got = oe.forward(spec, w, z[f"{case}.ids"][sub].astype(np.int64), z[f"{case}.mask"][sub].astype(np.int64), pool=str(z[f"{case}.pool"]))
+    np.testing.assert_allclose(got, z[f"{case}.emb"][sub], rtol=0, atol=5e-5)

@@ -150,6 +150,20 @@ def test_f6_hf_golden(golden_dir, case):
     np.testing.assert_allclose(got, z[f"{case}.emb"], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("case", ["minilm6", "bge12"])
+def test_f6b_hf_golden_full_depth(golden_dir, case):
+    """F6b (round 3): HF BertModel outputs at FULL depth -- all 6 layers of the MiniLM-L6 geometry, all 12 of bge-base, full
+    vocabulary -- vs the HIP encoder, atol 1e-3 (tests/golden/make_golden_encoder.py writes both fixture files)."""
+    from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, seeded_weights
+    z = np.load(golden_dir / "f6b_encoder_full.npz")
+    base = {"minilm6": "minilm-l6", "bge12": "bge-base"}[case]
+    assert int(z[f"{case}.layers"]) == oe.SPECS[base]["layers"]
+    spec = EncoderSpec(**oe.SPECS[base])
+    enc = HipSentenceEncoder(spec, seeded_weights(spec, int(z[f"{case}.seed"])))
+    got = enc.forward(z[f"{case}.ids"], z[f"{case}.mask"], pool=str(z[f"{case}.pool"]))
+    np.testing.assert_allclose(got, z[f"{case}.emb"], rtol=0, atol=TOL)
+
+
 def test_bf16_compute_and_errors():
     from mrag_amd.encoder import HipSentenceEncoder, EncoderSpec, ARCHS
     from mrag_amd._native import MragError
