@@ -99,6 +99,10 @@ int64_t bf_round_rows(int64_t n);     // rows rounded up to the kernel's tile (2
 //   [5],[6] float offset of the workgroup's score block S[slot][pitch] (low, high)        [7] pitch (floats, % 32 == 0)
 constexpr int IVFS_DESC_WORDS = 8;
 constexpr int IVFS_QUERIES = 128;       // queries per scan workgroup
+#ifndef MRAG_IVFS_CHUNK_ROWS
+#define MRAG_IVFS_CHUNK_ROWS 128
+#endif
+constexpr int IVFS_CHUNK_ROWS = MRAG_IVFS_CHUNK_ROWS;   // rows of a list one scan descriptor covers = one tile of the scan kernel (longer lists are cut: no single-workgroup tails)
 constexpr int IVFS_PITCH_ALIGN = 32;    // floats: every query's score segment starts on a 128-byte line
 static inline int64_t ivfs_pitch(int64_t rows) { return (rows + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN; }
 constexpr int IVFS_DENSE_ROWS = 128;    // corpus rows per descriptor of the dense (probe selection) case: one tile, so that the persistent grid balances

@@ -37,6 +37,7 @@ struct IvfIndex : Object {
   int max_list_rows = 0;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
+  DevBuf gsoff;                                // score-segment regime: float offset of every query group's score block
   DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
   bool last_scores_path = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | (unused) | (unused) | search end
@@ -48,7 +49,7 @@ struct IvfIndex : Object {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cev) if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
-    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc, &stats}) b->release();
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc, &stats, &gsoff}) b->release();
   }
 };
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ 
 __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
                                    const int* __restrict__ list_count, const int* __restrict__ wg_first,
                                    int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc, int qshift,
-                                   const int* __restrict__ sdesc, int4* __restrict__ pinfo) {
+                                   const long long* __restrict__ gsoff, const int* __restrict__ list_tile_lo, int4* __restrict__ pinfo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npairs) return;
   const int64_t l = probes[i];
@@ -148,80 +149,99 @@ __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t n
   const int wgi = wg_first[l] + (pos >> qshift), slot = pos & ((1 << qshift) - 1);   // 2^qshift queries per workgroup
   gq[((size_t)wgi << qshift) + slot] = i / nprobe;
   if (pinfo) {
-    // score-segment regime: everything the per-query selection needs about this pair, in one 16-byte record
-    const int* d = sdesc + (size_t)wgi * IVFS_DESC_WORDS;
-    const long long so = ((long long)(unsigned)d[5] | ((long long)d[6] << 32)) + (long long)slot * d[7];
-    pinfo[i] = make_int4((int)(unsigned)(so & 0xFFFFFFFFll), (int)(so >> 32), d[3], d[2]);
+    // score-segment regime: everything the per-query selection needs about this pair, in one 16-byte record -- its score
+    // segment (its group's block + slot x pitch), the rows and the first stored row of the whole LIST (the list's rows may be
+    // cut over several scan descriptors; every one of them writes its rows of this segment)
+    const int lc = list_count[l];
+    const long long pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
+    const long long so = gsoff[wgi] + (long long)slot * pitch;
+    pinfo[i] = make_int4((int)(unsigned)(so & 0xFFFFFFFFll), (int)(so >> 32), lc, list_tile_lo[l] * 256);
   } else {
     ploc[i] = make_int2(wgi, slot);
   }
 }
 
-// Plan of the "score segments + select" regime (ivf_scan.hip): workgroups of <= 128 queries, each list's scores
-// as one block S[query slot of the list][pitch = list rows rounded to 4]; out[0] = workgroups, out[1..2] = floats.
+// Plan of the "score segments + select" regime (ivf_scan.hip).  A list probed by cnt queries becomes ceil(cnt / 128) query
+// GROUPS (one block of scores S[query slot of the group][pitch = list rows rounded to 32] each, one block of 128 query-row
+// ids in gq each) x ceil(rows / IVFS_CHUNK_ROWS) row CHUNKS = that many scan descriptors: a long list (skewed data: thousands
+// of rows where the median list has a hundred) is scanned by several workgroups instead of being one workgroup's tail.
+// Measured (round 3, one box, whole search): chunk = whole list / 1024 / 512 / 256 / 128 rows -- C5 share (152-row lists) 0.743 /
+// - / 0.743 / 0.713 / 0.700 ms; 5 M rows (1 220-row lists) 4.02 / 3.81 / 3.64 / 3.51 / 3.56 ms; Zipf-sized lists (0 ... 5 330 rows),
+// nprobe 1 / 32: 0.98 / 1.38 -> 0.62 / 1.13 -> 0.61 / 1.05 -> 0.52 / 0.94 -> 0.50 / 0.94 ms.
+// out[0] = descriptors, out[1..2] = score floats; gsoff[group] = float offset of the group's block; wg_first[l] = first group.
 __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
                                                                const int* __restrict__ list_tile_lo, int nlist,
                                                                int* __restrict__ wg_first, int* __restrict__ cursor,
                                                                int* __restrict__ desc, int desc_cap, int* __restrict__ out,
-                                                               unsigned long long* __restrict__ stats) {
-  __shared__ int part[1024];
-  __shared__ long long fpart[1024];
-  __shared__ int carry;
+                                                               unsigned long long* __restrict__ stats, long long* __restrict__ gsoff,
+                                                               int group_cap) {
+  __shared__ int part[1024];          // groups
+  __shared__ int dpart[1024];         // descriptors
+  __shared__ long long fpart[1024];   // score floats
+  __shared__ int carry, dcarry;
   __shared__ long long fcarry;
   __shared__ unsigned long long rows_acc;
   const int tid = threadIdx.x;
-  if (tid == 0) { carry = 0; fcarry = 0; rows_acc = 0ull; }
+  if (tid == 0) { carry = 0; dcarry = 0; fcarry = 0; rows_acc = 0ull; }
   __syncthreads();
   for (int base = 0; base < nlist; base += 1024) {
     const int l = base + tid;
     const int cnt = l < nlist ? lcount[l] : 0;
     const int lc = l < nlist ? list_count[l] : 0;
     const int nt = (cnt + IVFS_QUERIES - 1) / IVFS_QUERIES;
+    const int nch = (lc + IVFS_CHUNK_ROWS - 1) / IVFS_CHUNK_ROWS;
     if (nt && lc) atomicAdd(&rows_acc, (unsigned long long)nt * (unsigned long long)lc);   // rows this list's workgroups stream
     const int pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
     const long long fl = (long long)cnt * pitch;
     part[tid] = nt;
+    dpart[tid] = nt * nch;
     fpart[tid] = fl;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {           // inclusive scans (Hillis-Steele)
       const int v = tid >= off ? part[tid - off] : 0;
+      const int dv = tid >= off ? dpart[tid - off] : 0;
       const long long fv = tid >= off ? fpart[tid - off] : 0;
       __syncthreads();
       part[tid] += v;
+      dpart[tid] += dv;
       fpart[tid] += fv;
       __syncthreads();
     }
     const int first = carry + part[tid] - nt;
+    const int dfirst = dcarry + dpart[tid] - nt * nch;
     const long long foff = fcarry + fpart[tid] - fl;
     if (l < nlist) {
       wg_first[l] = first;
       cursor[l] = 0;
       const int tlo = list_tile_lo[l];
       for (int c = 0; c < nt; ++c) {
-        const int wgi = first + c;
-        if (wgi < desc_cap) {
-          int* d = desc + (size_t)wgi * IVFS_DESC_WORDS;
-          const long long so = foff + (long long)c * IVFS_QUERIES * pitch;
-          d[0] = wgi * IVFS_QUERIES;
-          d[1] = min(IVFS_QUERIES, cnt - c * IVFS_QUERIES);
-          d[2] = tlo * 256;
-          d[3] = lc;
-          d[4] = 0;
-          d[5] = (int)(unsigned)(so & 0xFFFFFFFFll);
-          d[6] = (int)(so >> 32);
-          d[7] = pitch;
+        const long long so = foff + (long long)c * IVFS_QUERIES * pitch;
+        if (first + c < group_cap) gsoff[first + c] = so;
+        for (int r = 0; r < nch; ++r) {
+          const int di = dfirst + c * nch + r;
+          if (di < desc_cap) {
+            int* d = desc + (size_t)di * IVFS_DESC_WORDS;
+            d[0] = (first + c) * IVFS_QUERIES;
+            d[1] = min(IVFS_QUERIES, cnt - c * IVFS_QUERIES);
+            d[2] = tlo * 256 + r * IVFS_CHUNK_ROWS;
+            d[3] = min(IVFS_CHUNK_ROWS, lc - r * IVFS_CHUNK_ROWS);
+            d[4] = r * IVFS_CHUNK_ROWS;
+            d[5] = (int)(unsigned)(so & 0xFFFFFFFFll);
+            d[6] = (int)(so >> 32);
+            d[7] = pitch;
+          }
         }
       }
     }
     __syncthreads();
-    if (tid == 1023) { carry += part[1023]; fcarry += fpart[1023]; }
+    if (tid == 1023) { carry += part[1023]; dcarry += dpart[1023]; fcarry += fpart[1023]; }
     __syncthreads();
   }
   if (tid == 0) {
-    out[0] = carry;
+    out[0] = dcarry;
     out[1] = (int)(unsigned)(fcarry & 0xFFFFFFFFll);
     out[2] = (int)(fcarry >> 32);
-    if (stats) { atomicAdd(&stats[0], rows_acc); atomicAdd(&stats[1], (unsigned long long)carry); }
+    if (stats) { atomicAdd(&stats[0], rows_acc); atomicAdd(&stats[1], (unsigned long long)dcarry); }
   }
 }
 
@@ -597,8 +617,11 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   //    kernel) queries.  Only the workgroup count and the size of the segments come back to the host (12 bytes).
   const size_t npairs = (size_t)nq * nprobe;
   const int64_t wg_bound = (int64_t)std::min<size_t>((size_t)nl, npairs) + (int64_t)(npairs / IVFS_QUERIES) + 1;   // (covers the 256-query plan too)
-  MRAG_TRY(ix->desc.ensure((size_t)wg_bound * 8 * 4));
+  // score-segment regime: every group is cut into ceil(list rows / IVFS_CHUNK_ROWS) scan descriptors
+  const int64_t desc_bound = wg_bound * std::max<int64_t>(1, (ix->max_list_rows + IVFS_CHUNK_ROWS - 1) / IVFS_CHUNK_ROWS);
+  MRAG_TRY(ix->desc.ensure((size_t)desc_bound * 8 * 4));
   MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
+  MRAG_TRY(ix->gsoff.ensure((size_t)wg_bound * 8));
   MRAG_TRY(ix->ploc.ensure(npairs * 16));   // int2 (fused regime) or int4 (score segments) per pair
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
   if (!counted)
@@ -614,7 +637,8 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   const bool planned_scores = use_scores;
   if (use_scores) {
     hipLaunchKernelGGL(ivf_plan_scores_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
-                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)wg_bound, d_nwg, d_stats);
+                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)desc_bound, d_nwg, d_stats,
+                       (long long*)ix->gsoff.p, (int)wg_bound);
     MRAG_HIP(hipGetLastError());
     if (no_sync) {
       MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>((int64_t)npairs * max_pitch, 4) * 4));
@@ -622,7 +646,7 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
       MRAG_HIP(hipMemcpyAsync(plan_out, d_nwg, 12, hipMemcpyDeviceToHost, stream));
       MRAG_HIP(hipStreamSynchronize(stream));
       const int64_t floats = (int64_t)(uint32_t)plan_out[1] | ((int64_t)plan_out[2] << 32);
-      if (plan_out[0] < 0 || plan_out[0] > wg_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", plan_out[0], (long long)wg_bound);
+      if (plan_out[0] < 0 || plan_out[0] > desc_bound) return fail(MRAG_ERR_HIP, "IVF plan produced %d workgroups (bound %lld)", plan_out[0], (long long)desc_bound);
       if (floats * 4 > scores_cap) use_scores = false;
       else MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>(floats, 4) * 4));
     }
@@ -631,18 +655,18 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   if (use_scores) {
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, nullptr, 7,
-                       (const int*)ix->desc.p, (int4*)ix->ploc.p);
+                       (const long long*)ix->gsoff.p, (const int*)ix->d_list_tile_lo.p, (int4*)ix->ploc.p);
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
     MRAG_HIP(hipEventRecord(ev_scan0, stream));
     static const char* stamp_path = getenv("MRAG_IVFS_STAMPS");   // diagnostic builds (MRAG_IVFS_DIAG & 128): per-workgroup clock stamps -> file
     long long* dbg = nullptr;
-    if (stamp_path) { MRAG_TRY(ix->qg.ensure((size_t)wg_bound * 64)); MRAG_HIP(hipMemsetAsync(ix->qg.p, 0, (size_t)wg_bound * 64, stream)); dbg = (long long*)ix->qg.p; }
+    if (stamp_path) { MRAG_TRY(ix->qg.ensure((size_t)desc_bound * 64)); MRAG_HIP(hipMemsetAsync(ix->qg.p, 0, (size_t)desc_bound * 64, stream)); dbg = (long long*)ix->qg.p; }
     if (no_sync) {
-      MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, (int)wg_bound, d_nwg,
+      MRAG_TRY(ivfs_scan(ix->sorted, (const uint16_t*)ix->qbuf.p, ix->ld, ix->dtype, nq, (const int*)ix->desc.p, (int)desc_bound, d_nwg,
                          (const int64_t*)ix->gq.p, (float*)ix->scores.p, stream, dbg));
       if (stamp_path) {
-        std::vector<long long> h((size_t)wg_bound * 8);
+        std::vector<long long> h((size_t)desc_bound * 8);
         MRAG_HIP(hipStreamSynchronize(stream));
         MRAG_HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(stamp_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
@@ -661,7 +685,7 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
                        planned_scores ? nullptr : d_stats);   // (a scores plan that turned out too big has already counted this chunk)
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8,
-                       nullptr, nullptr);
+                       nullptr, nullptr, nullptr);
     MRAG_HIP(hipGetLastError());
     MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipStreamSynchronize(stream));
