@@ -88,13 +88,24 @@ class HashingTokenizer:
 
     PAD, CLS, SEP = 0, 101, 102
 
+    _WORD = re.compile(r"[a-z0-9]+")
+
     def __init__(self, vocab_size: int):
         self.vocab_size = vocab_size
         self.lo = min(1000, max(3, vocab_size // 10))
+        self._ids: Dict[str, int] = {}          # token -> id memo (natural text repeats its words: corpus ingest is tokeniser-bound)
+
+    def _id(self, t: str) -> int:
+        v = self._ids.get(t)
+        if v is None:
+            v = self.lo + zlib.crc32(t.encode()) % (self.vocab_size - self.lo)
+            if len(self._ids) < 1_000_000:
+                self._ids[t] = v
+        return v
 
     def encode(self, text: str, max_length: int) -> List[int]:
-        toks = [t for t in re.split(r"[^a-zA-Z0-9]+", (text or "").lower()) if t]
-        ids = [self.lo + zlib.crc32(t.encode()) % (self.vocab_size - self.lo) for t in toks][: max_length - 2]
+        # (same tokens as re.split(r"[^a-zA-Z0-9]+", text.lower()) minus the empty strings)
+        ids = [self._id(t) for t in self._WORD.findall((text or "").lower())[: max_length - 2]]
         cls, sep = min(self.CLS, self.vocab_size - 1), min(self.SEP, self.vocab_size - 1)
         return [cls] + ids + [sep]
 
@@ -111,6 +122,10 @@ class WordPieceTokenizer:
 
     def encode(self, text: str, max_length: int) -> List[int]:
         return self._truncate(self._tok.encode(text or "").ids, max_length)
+
+    def encode_batch(self, texts: List[str], max_length: int) -> List[List[int]]:
+        """Many texts at once through the library's multi-threaded ``encode_batch`` (bulk ingest)."""
+        return [self._truncate(e.ids, max_length) for e in self._tok.encode_batch([t or "" for t in texts])]
 
     @staticmethod
     def _truncate(ids: List[int], max_length: int) -> List[int]:
@@ -264,7 +279,10 @@ class HipSentenceEncoder:
         return ms.value
 
     def tokenize(self, texts: List[str]):
-        seqs = [self.tokenizer.encode(t, self.max_length) for t in texts]
+        if hasattr(self.tokenizer, "encode_batch") and len(texts) > 8:
+            seqs = self.tokenizer.encode_batch(texts, self.max_length)
+        else:
+            seqs = [self.tokenizer.encode(t, self.max_length) for t in texts]
         S = max(16, -(-max(len(s) for s in seqs) // 16) * 16)
         S = min(S, self.spec.max_position)
         ids = np.zeros((len(seqs), S), dtype=np.int32)
