@@ -698,10 +698,17 @@ __device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
     // selection with the scores streamed twice instead of held in registers.  Pass 1: every thread's maximum over its
     // entries (segment by segment, entry t of a segment on thread t mod 256: coalesced, 8 loads in flight) -> the k-th
     // largest thread maximum P, a lower bound of the k-th best score.  Pass 2: the entries >= P are the shortlist.
+    // (pass 1 only needs SOME k entries' lower bound: it reads the leading segments -- the best-ranked probes, where most of
+    // the answer sits -- until it has seen `want` entries: enough that the entries >= P over ALL segments stay a shortlist of
+    // ~ k (total / want)(1 + k / 256) <= ~384 entries; 5 M rows, k = 10: 8 192 of ~39 000 entries, selection 1.24 -> 0.9 ms)
+    const long long need = ((long long)total * k * (256 + k) / 256 + 383) / 384;
+    const int want = (int)(need > total ? total : need < SEL_CAP ? SEL_CAP : need);
     uint32_t tmax = 0u;
-    for (int j = 0; j < np; ++j) {
+    int seen = 0;
+    for (int j = 0; j < np && seen < want; ++j) {
       const float* sp = seg_ptr[j];
       const int cnt = seg_cnt[j];
+      seen += cnt;
 #pragma unroll 8
       for (int t = tid; t < cnt; t += SEL_THR) {
         const uint32_t key = s_f32_ord(sp[t]);

@@ -25,7 +25,12 @@ Rank 0 prints ONE JSON line.  Besides the contract keys:
   c2_roofline          ... and at config C2, 1 000 x 100 000 x 768 (N=1)
   online_roofline      1 query per call (the reference's own usage): streaming kernel, HBM-bound
   ivf_roofline         config C5 on one GPU's share (625 000 x 768, nlist 4096, nprobe 32, 10 k queries):
-                       list scan (score-segment scan + per-query select kernels), bytes = rows streamed x 768 x 2 (N=1)
+                       list scan (score-segment scan + per-query select kernels), bytes = rows streamed x 768 x 2 (N=1);
+                       its cpu_baseline = the numpy IVF restatement on a bounded query sample
+  ivf_roofline_5m      the same over the WHOLE 5 M x 768 corpus on one GPU (7.7 GB; C5's N = 1 point)
+  ivf_skewed           recall@10 and search ms vs nprobe on Zipf-sized, overlapping clusters (not the best case)
+  ingest_from_text     C3's 64 k passages, text -> tokens -> bge-base forward -> index, passages/s
+  step_phases_ms       per-phase device ms of a step (local search, pack, all-gather, merge, D2H); N > 1: two_half_pipeline
   encoder_roofline     config C3 shape (bge-base, 2048 passages x 128 tokens): device ms of the forward (N=1)
   cpu_baseline         N=1: the numpy restatement (oracle.dense_search.brute_force_topk_f32: sgemm + top-k on
                        the same fp16-rounded rows) timed on this host's cores on a bounded query sample
@@ -155,9 +160,10 @@ def ivf_leg(device, k, n=625_000, with_cpu=False):
             "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
             "bytes_per_launch": nbytes, "rows_streamed": t["scanned_rows"], "workgroups": t["n_wg"],
             "recall_at_10_vs_brute_force": rec,
-            "note": "algorithmic bytes = list rows streamed once per (list, <=128 probing queries) workgroup; kernel_ms covers the scan "
-                    "AND the selection. The scan also moves the gathered query rows (nq x nprobe x 1.5 KB from the fabric) and "
-                    "4 B per (query, row) score out and back: about twice the algorithmic bytes"}
+            "note": "algorithmic bytes = list rows streamed once per (list, <=128 probing queries) group (a list is cut into 128-row scan "
+                    "descriptors); kernel_ms covers the scan AND the selection. The scan also moves the gathered query rows (nq x nprobe x "
+                    "1.5 KB from the fabric) and 4 B per (query, row) score out and back: about twice the algorithmic bytes "
+                    "(counter: profiles/r03*_counters.json, ivfs_scan_kernel traffic per launch)"}
 
 
 def ivf_skewed_leg(device, k):
