@@ -700,7 +700,7 @@ __device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
     // largest thread maximum P, a lower bound of the k-th best score.  Pass 2: the entries >= P are the shortlist.
     // (pass 1 only needs SOME k entries' lower bound: it reads the leading segments -- the best-ranked probes, where most of
     // the answer sits -- until it has seen `want` entries: enough that the entries >= P over ALL segments stay a shortlist of
-    // ~ k (total / want)(1 + k / 256) <= ~384 entries; 5 M rows, k = 10: 8 192 of ~39 000 entries, selection 1.24 -> 0.9 ms)
+    // ~ k (total / want)(1 + k / 256) <= ~384 entries; 5 M rows, k = 10: 8 192 of ~39 000 entries, selection 1.24 -> 0.93 ms)
     const long long need = ((long long)total * k * (256 + k) / 256 + 383) / 384;
     const int want = (int)(need > total ? total : need < SEL_CAP ? SEL_CAP : need);
     uint32_t tmax = 0u;
@@ -719,10 +719,16 @@ __device__ __forceinline__ void ivfs_select_body(const SelParams& p) {
     for (int j = 0; j < np; ++j) {
       const float* sp = seg_ptr[j];
       const int cnt = seg_cnt[j], pre = seg_pre[j];
-      for (int t0 = 0; t0 < cnt; t0 += SEL_THR) {          // (uniform trip count: the append's ballot needs the wave converged)
-        const int t = t0 + tid;
-        const uint32_t key = t < cnt ? s_f32_ord(sp[t]) : 0u;
-        shortlist_append(t < cnt && key >= P, key, pre + t);
+      for (int t0 = 0; t0 < cnt; t0 += 8 * SEL_THR) {      // (uniform trip count: the append's ballot needs the wave converged)
+        float raw[8];                                      // eight loads in flight per thread, then the (rare) appends
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int t = t0 + u * SEL_THR + tid; raw[u] = t < cnt ? sp[t] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + u * SEL_THR + tid;
+          const uint32_t key = t < cnt ? s_f32_ord(raw[u]) : 0u;
+          shortlist_append(t < cnt && key >= P, key, pre + t);
+        }
       }
     }
     if (!rank_shortlist()) serial = true;
