@@ -323,7 +323,13 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} is running under a launcher with WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
-    if n_dev < world or local_rank >= n_dev:
+    # REHEARSAL switch (never what the driver runs): MRAG_BENCH_REHEARSE=1 puts every rank on cuda:0 and moves the exchange over
+    # gloo (which carries CUDA tensors too), so that the N > 1 code path of this file can be executed end to end on a one-GPU box;
+    # the line it prints says so in `config.rehearsal` and is not a scaling measurement
+    rehearse = os.environ.get("MRAG_BENCH_REHEARSE", "") not in ("", "0")
+    if rehearse:
+        local_rank = 0
+    if n_dev < (1 if rehearse else world) or local_rank >= n_dev:
         raise SystemExit(f"bench.py --gpus {world} needs {world} visible MI355X devices, this box has {n_dev}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CUDA/HIP device visible")
@@ -331,7 +337,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from mrag_amd.sharded import ShardedDenseIndex
 
@@ -486,7 +495,8 @@ def main():
             "config": {"workload": "C4: 10k-query batch x 1M x 768 fp16 corpus, k=10, corpus row-sharded across GPUs, "
                                    "one all-gather of packed (score, id) partial top-k + device merge",
                        "n_queries": nq, "n_corpus": n, "dim": d, "k": k,
-                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}"},
+                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
+                       **({"rehearsal": "all ranks on ONE GPU, exchange over gloo: exercises the N > 1 code path, not a scaling number"} if rehearse else {})},
             "median_ms_per_step": float(np.median(step_ms)),
             "value_incl_h2d": nq * n_h2d / elapsed_h2d,
             "value_incl_h2d_pipelined": nq * n_h2d / elapsed_h2d_pipe,
