@@ -67,6 +67,8 @@ SIGNATURES = {
     "mrag_index_last_clock": [_h, _fp],
     "mrag_topk_merge": [_vp, _vp, _i, _i64, _i, _vp, _vp, _i],
     "mrag_topk_merge_device": [_i, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp],
+    "mrag_pack_partial_device": [_i, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "mrag_topk_merge_packed_device": [_i, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp],
     "mrag_ivf_create": [_i, _i, _i, _i, _i, C.POINTER(_h)],
     "mrag_ivf_destroy": [_h],
     "mrag_ivf_train": [_h, _vp, _i64, _i, _i, _i, _i, C.c_uint64, _vp],

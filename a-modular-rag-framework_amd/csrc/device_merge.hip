@@ -13,6 +13,8 @@ constexpr int DM_MAX_CAND = 2048;   // nparts * k staged per query (24 KiB of LD
 struct DmParams {
   const float* scores;    // [nparts][nq][k]
   const int64_t* ids;     // [nparts][nq][k]
+  const int64_t* words;   // packed form instead of (scores, ids): (score bits << 32) | shard-local row, 0xFFFFFFFF = empty slot
+  const int64_t* bases;   // packed form: first global row of every part [nparts]
   int nparts, k;
   int64_t nq;
   float* out_scores;      // [nq][k]
@@ -36,8 +38,15 @@ __global__ __launch_bounds__(64) void topk_merge_device_kernel(DmParams p) {
   for (int c = lane; c < total; c += 64) {
     const int part = c / k, i = c - part * k;
     const size_t src = ((size_t)part * p.nq + q) * k + i;
-    s_sc[c] = p.scores[src];
-    s_id[c] = p.ids[src];
+    if (p.words) {   // the all-gather's packed words, unpacked on the way into LDS (no separate unpack pass over the gathered buffer)
+      const int64_t wv = p.words[src];
+      const uint32_t low = (uint32_t)(wv & 0xFFFFFFFFll);
+      s_sc[c] = __uint_as_float((uint32_t)((uint64_t)wv >> 32));
+      s_id[c] = low == 0xFFFFFFFFu ? (int64_t)-1 : (int64_t)low + p.bases[part];
+    } else {
+      s_sc[c] = p.scores[src];
+      s_id[c] = p.ids[src];
+    }
   }
   __syncthreads();
   if (lane < np) {   // valid prefix length of the (sorted, empties last) part
@@ -74,8 +83,35 @@ __global__ __launch_bounds__(64) void topk_merge_device_kernel(DmParams p) {
   }
 }
 
+// (score, global id) -> packed word of the exchange; ids outside [id_base, id_base + 2^32 - 1) raise a flag (never wrapped)
+__global__ void pack_partial_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids, int64_t n, int64_t id_base,
+                                    int64_t* __restrict__ words, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t id = ids[i];
+  uint32_t low = 0xFFFFFFFFu;
+  if (id >= 0) {
+    const int64_t local = id - id_base;
+    if (local < 0 || local >= 0xFFFFFFFFll) { if (bad) atomicOr(bad, 1); }
+    low = (uint32_t)local;
+  }
+  words[i] = (int64_t)(((uint64_t)__float_as_uint(scores[i]) << 32) | (uint64_t)low);
+}
+
 }  // namespace
 }  // namespace mrag
+
+extern "C" int mrag_pack_partial_device(int device, const float* scores, const int64_t* ids, int64_t n, int64_t id_base,
+                                        int64_t* words, int* bad_flag, void* stream) {
+  using namespace mrag;
+  if (n < 0) return fail(MRAG_ERR_INVALID, "bad n");
+  if (n == 0) return MRAG_OK;
+  if (!scores || !ids || !words) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  MRAG_TRY(use_device(device));
+  hipLaunchKernelGGL(pack_partial_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, ids, n, id_base, words, bad_flag);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
 
 extern "C" int mrag_topk_merge_device(int device, const float* scores, const int64_t* ids, int nparts, int64_t nq, int k,
                                       float* out_scores, int64_t* out_ids, void* stream) {
@@ -87,7 +123,23 @@ extern "C" int mrag_topk_merge_device(int device, const float* scores, const int
                 DM_MAX_CAND, nparts, k);
   MRAG_TRY(use_device(device));
   if (nq == 0) return MRAG_OK;
-  DmParams p{scores, ids, nparts, k, nq, out_scores, out_ids};
+  DmParams p{scores, ids, nullptr, nullptr, nparts, k, nq, out_scores, out_ids};
+  hipLaunchKernelGGL(topk_merge_device_kernel, dim3((unsigned)nq), dim3(64), 0, (hipStream_t)stream, p);
+  MRAG_HIP(hipGetLastError());
+  return MRAG_OK;
+}
+
+extern "C" int mrag_topk_merge_packed_device(int device, const int64_t* words, const int64_t* bases, int nparts, int64_t nq, int k,
+                                             float* out_scores, int64_t* out_ids, void* stream) {
+  using namespace mrag;
+  if (!words || !bases || !out_scores || !out_ids) return fail(MRAG_ERR_INVALID, "NULL buffer");
+  if (nparts <= 0 || nq < 0 || k <= 0) return fail(MRAG_ERR_INVALID, "nparts = %d, nq = %lld, k = %d", nparts, (long long)nq, k);
+  if (nparts > 64 || (int64_t)nparts * k > DM_MAX_CAND)
+    return fail(MRAG_ERR_UNSUPPORTED, "device merge serves nparts <= 64 and nparts * k <= %d (got %d x %d); use mrag_topk_merge",
+                DM_MAX_CAND, nparts, k);
+  MRAG_TRY(use_device(device));
+  if (nq == 0) return MRAG_OK;
+  DmParams p{nullptr, nullptr, words, bases, nparts, k, nq, out_scores, out_ids};
   hipLaunchKernelGGL(topk_merge_device_kernel, dim3((unsigned)nq), dim3(64), 0, (hipStream_t)stream, p);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;

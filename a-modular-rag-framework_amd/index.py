@@ -247,6 +247,37 @@ def topk_merge_device(scores, ids, out_scores=None, out_ids=None):
     return out_scores, out_ids
 
 
+def pack_partial_device(scores, ids, id_base: int, out_words=None, bad_flag=None):
+    """[Q,k] fp32 scores + int64 global ids (CUDA) -> the exchange's packed int64 words in ONE kernel (``mrag_pack_partial_device``;
+    the torch form in ``sharded.pack_partial`` is ~8 elementwise kernels).  ``bad_flag``: int32 CUDA tensor [1], OR'ed with 1 when
+    an id does not fit 32 bits above ``id_base``.  Asynchronous on the current stream."""
+    import torch
+    scores, ids = scores.contiguous(), ids.contiguous()
+    if out_words is None:
+        out_words = torch.empty(scores.shape, dtype=torch.int64, device=scores.device)
+    stream = torch.cuda.current_stream(scores.device).cuda_stream
+    N.check(N.load().mrag_pack_partial_device(scores.device.index or 0, scores.data_ptr(), ids.data_ptr(), scores.numel(), int(id_base),
+                                              out_words.data_ptr(), bad_flag.data_ptr() if bad_flag is not None else None, stream))
+    return out_words
+
+
+def topk_merge_packed_device(words, bases, out_scores=None, out_ids=None):
+    """Merge of the GATHERED packed words [nparts, nq, k] (int64 CUDA) with the parts' first global rows ``bases`` (int64 CUDA
+    [nparts]) -> CUDA tensors [nq, k] (``mrag_topk_merge_packed_device``): no unpack pass over the gathered buffer."""
+    import torch
+    words = words.contiguous()
+    nparts, nq, k = words.shape
+    dev = words.device
+    if out_scores is None:
+        out_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    if out_ids is None:
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    N.check(N.load().mrag_topk_merge_packed_device(dev.index or 0, words.data_ptr(), bases.contiguous().data_ptr(), nparts, nq, k,
+                                                   out_scores.data_ptr(), out_ids.data_ptr(), stream))
+    return out_scores, out_ids
+
+
 class IVFFlatIndex:
     """IVF-flat index on one GPU (BASELINE.json config 5): nlist spherical-k-means lists, every
     search probes the ``nprobe`` best lists and scans them exactly.  Same id / tie-break

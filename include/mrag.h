@@ -133,6 +133,15 @@ int mrag_topk_merge(const float* scores, const int64_t* ids, int nparts, int64_t
  * nparts * k <= 2048; larger requests return MRAG_ERR_UNSUPPORTED (use the host merge). */
 int mrag_topk_merge_device(int device, const float* scores, const int64_t* ids, int nparts, int64_t nq, int k,
                            float* out_scores, int64_t* out_ids, void* stream);
+/* the exchange's packed form (ONE all-gather of 8-byte words): word = (fp32 score bits << 32) | shard-local row
+ * (id - id_base as 32 bits; 0xFFFFFFFF = empty slot).  pack: n = nq * k device entries -> words; an id outside
+ * [id_base, id_base + 2^32 - 1) ORs 1 into *bad_flag (device int, may be NULL) -- nothing is wrapped silently.
+ * merge_packed: the gathered words [nparts, nq, k] + the parts' first global rows bases[nparts] (device) -> [nq, k], same order
+ * and limits as mrag_topk_merge_device (the words are unpacked on their way into LDS: no pass over the gathered buffer). */
+int mrag_pack_partial_device(int device, const float* scores, const int64_t* ids, int64_t n, int64_t id_base,
+                             int64_t* words, int* bad_flag, void* stream);
+int mrag_topk_merge_packed_device(int device, const int64_t* words, const int64_t* bases, int nparts, int64_t nq, int k,
+                                  float* out_scores, int64_t* out_ids, void* stream);
 
 /* ---- IVF-flat (BASELINE.json config 5; no counterpart in the reference) ----------- */
 int mrag_ivf_create(int dim, int nlist, int metric, int storage_dtype, int device, mrag_handle* out);

@@ -327,6 +327,51 @@ def test_device_merge_matches_host_merge(nparts, nq, k, pool):
     assert np.array_equal(ds_.cpu().numpy(), hs)
 
 
+def test_packed_exchange_kernels_match_the_torch_forms():
+    """The exchange's one-kernel forms: ``mrag_pack_partial_device`` == ``sharded.pack_partial`` bit for bit (empties, ids up to
+    base + 2^32 - 2, -0.0 / -inf / denormal scores), its flag fires for an id below the base or beyond 32 bits, and
+    ``mrag_topk_merge_packed_device`` over gathered words == ``mrag_topk_merge`` over the unpacked arrays."""
+    import torch
+    from mrag_amd.index import pack_partial_device, topk_merge, topk_merge_packed_device
+    from mrag_amd.sharded import pack_partial, unpack_partial
+    rng = np.random.default_rng(12)
+    nparts, nq, k = 5, 333, 10
+    bases = np.array([0, 7_000_000_000, 7_000_000_000 + 2**31, 9_123_456_789, 2**40], dtype=np.int64)
+    sc = np.full((nparts, nq, k), -np.inf, dtype=np.float32)
+    ids = np.full((nparts, nq, k), -1, dtype=np.int64)
+    for p_ in range(nparts):
+        for q in range(nq):
+            m = int(rng.integers(0, k + 1))
+            v = np.sort(rng.integers(-3, 9, size=m).astype(np.float32) / 4)[::-1]
+            sc[p_, q, :m] = v
+            loc = np.sort(rng.choice(2**32 - 2, size=m, replace=False)) if m else np.empty(0, np.int64)
+            order = np.lexsort((loc, -v)) if m else []
+            ids[p_, q, :m] = bases[p_] + loc[order] if m else []
+            sc[p_, q, :m] = v[order] if m else []
+    for (p_, q, val) in ((0, 0, 3.0e-39), (1, 1, -0.0)):          # single-entry parts with a denormal / a negative zero
+        sc[p_, q, :] = -np.inf; ids[p_, q, :] = -1
+        sc[p_, q, 0] = val; ids[p_, q, 0] = bases[p_] + 17
+    words = []
+    for p_ in range(nparts):
+        s_t, i_t = torch.from_numpy(sc[p_]).cuda(), torch.from_numpy(ids[p_]).cuda()
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        w = pack_partial_device(s_t, i_t, int(bases[p_]), bad_flag=flag)
+        assert torch.equal(w, pack_partial(s_t, i_t, int(bases[p_]))) and int(flag.item()) == 0
+        words.append(w)
+    gw = torch.stack(words)
+    gs, gi = unpack_partial(gw, torch.from_numpy(bases).cuda().view(nparts, 1, 1))
+    assert torch.equal(gi.cpu(), torch.from_numpy(ids)) and torch.equal(gs.cpu().view(torch.int32), torch.from_numpy(sc).view(torch.int32))
+    ms, mi = topk_merge_packed_device(gw, torch.from_numpy(bases).cuda())
+    hs, hi = topk_merge(sc, ids)
+    torch.cuda.synchronize()
+    assert (mi.cpu().numpy() == hi).all() and np.array_equal(ms.cpu().numpy(), hs)
+    for bad_id in (int(bases[1]) - 1, int(bases[1]) + 2**32 - 1):
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        i_bad = torch.from_numpy(ids[1]).cuda().clone(); i_bad[3, 0] = bad_id
+        pack_partial_device(torch.from_numpy(sc[1]).cuda(), i_bad, int(bases[1]), bad_flag=flag)
+        assert int(flag.item()) == 1
+
+
 def test_device_merge_limits_are_loud():
     import torch
     from mrag_amd import _native as N
