@@ -453,7 +453,14 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   constexpr int WN = 16 / NF;            // waves along the query dimension
   constexpr int NW = 2 * WN;             // waves per workgroup
   constexpr int NT = 64 * NW;            // threads per workgroup
-  constexpr int CPW = 32 / NW;           // 1-KiB DMA chunks per wave per operand and stage
+  // Wave roles (MRAG_K2_ROLES=1): only waves 0-3 (one per SIMD) issue the LDS-DMA loads of a stage, 16 each instead of 8 from
+  // every wave: the SIMD partner of a loading wave goes straight to its fragment reads and MFMAs, so the two waves of a SIMD
+  // stop hitting their DMA issues, their read bursts and the barrier together.
+#ifndef MRAG_K2_ROLES
+#define MRAG_K2_ROLES 0
+#endif
+  constexpr bool ROLES = MRAG_K2_ROLES != 0 && NW == 8;
+  constexpr int CPW = ROLES ? 8 : 32 / NW;           // 1-KiB DMA chunks per (loading) wave per operand and stage
   constexpr int QPW = TQ / NW;           // queries whose lists a wave owns (compaction)
   typedef typename Mfma<DT>::frag frag;
   const int tid = threadIdx.x;
@@ -528,7 +535,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   const uint32_t row_b = (uint32_t)p.ld * 2u;                       // bytes per row
   const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);        // even chunks
   const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);  // odd chunks
-  const char* q_ptr = (const char*)(p.queries + (size_t)q_row0 * p.ld) + (size_t)(CPW * w) * 8 * row_b;
+  const int lw = ROLES ? (w & 3) : w;          // loading wave's slot
+  const bool loader = !ROLES || w < 4;
+  const char* q_ptr = (const char*)(p.queries + (size_t)q_row0 * p.ld) + (size_t)(CPW * lw) * 8 * row_b;
   const size_t tile_bytes = (size_t)TM * p.ld * 2;
   const uint32_t chunk_b = 8u * row_b;                               // 8 rows
 
@@ -536,11 +545,13 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
   // asm two at a time.  hipcc does not count them: every wait for them is an explicit s_waitcnt vmcnt
   // below.  M0 (LDS destination base) is written inside the statement that uses it and restored after.
   f32x4 dbg_sink0 = {0.f, 0.f, 0.f, 0.f}, dbg_sink1 = {0.f, 0.f, 0.f, 0.f};   // diag 16384 only
-  auto stage_part = [&](const char* a, const char* b, int buf, int part) {   // part 0,1: corpus chunks; 2,3: query chunks
-    const int op = part >> 1, i = (part & 1) * 2;
-    if (op == 1 && (CPW * w + i) * 8 >= nq_local && DESC) return;
+  constexpr int NPART = CPW;   // two chunks per part, two operands
+  auto stage_part = [&](const char* a, const char* b, int buf, int part) {   // first half of the parts: corpus chunks; second half: query chunks
+    if (!loader) return;
+    const int op = part / (NPART / 2), i = (part % (NPART / 2)) * 2;
+    if (op == 1 && (CPW * lw + i) * 8 >= nq_local && DESC) return;
     const char* base = op ? b : a;
-    const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * w + i) * 1024);   // wave-uniform
+    const uint32_t la = (uint32_t)(buf * STAGE_BYTES + op * A_BYTES + (CPW * lw + i) * 1024);   // wave-uniform
     const char* c0 = base + (size_t)i * chunk_b;
     const char* c1 = c0 + chunk_b;
     uint32_t keep;
@@ -565,9 +576,9 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     }
   };
   auto stage = [&](const char* a, const char* b, int buf) {
-    static_assert(CPW == 4, "stage_part covers 4 chunks per operand and wave");
+    static_assert(CPW == 4 || CPW == 8, "stage_part covers 4 or 8 chunks per operand and wave");
 #pragma unroll
-    for (int part = 0; part < 4; ++part) stage_part(a, b, buf, part);
+    for (int part = 0; part < NPART; ++part) stage_part(a, b, buf, part);
   };
 
   // ---- fragment read offsets ------------------------------------------------------------
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
 
   // prefetch cursor: (tile, k step) of the NEXT stage to issue, advanced with scalar adds only
   const int n_tiles = tile_hi - tile_lo;
-  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(CPW * w) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
+  const char* a_tile = (const char*)p.corpus + (size_t)tile_lo * tile_bytes + (size_t)(CPW * lw) * 8 * row_b;   // tile being prefetched (+ this wave's row block)
   int pf_kk = 0, pf_left = n_tiles * ksteps;
   // K walk direction (MRAG_ZZ, see the top of the file): 0 = every corpus tile first-to-last (shipped)
   int pf_tile = (MRAG_ZZ == 2) ? 0 : tile_lo;
@@ -624,8 +635,12 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
     if (do_stage) {
       --pf_left;
       if (++pf_kk == ksteps) { pf_kk = 0; a_tile += tile_bytes; ++pf_tile; }
-      stage_part(st_a, st_b, st_buf, 0);
-      if (!PENDING || MRAG_DBG(8)) { stage_part(st_a, st_b, st_buf, 1); stage_part(st_a, st_b, st_buf, 2); stage_part(st_a, st_b, st_buf, 3); }
+#pragma unroll
+      for (int pp = 0; pp < NPART / 4; ++pp) stage_part(st_a, st_b, st_buf, pp);
+      if (!PENDING || MRAG_DBG(8)) {
+#pragma unroll
+        for (int pp = NPART / 4; pp < NPART; ++pp) stage_part(st_a, st_b, st_buf, pp);
+      }
     }
     const char* sb = smem + buf * STAGE_BYTES;
     buf ^= 1;
@@ -653,7 +668,10 @@ __global__ __launch_bounds__(64 * 2 * (16 / NF), NF == 4 ? 2 : 1) void bf_gemm_t
             for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = Mfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
           if (part < 3) {
             __builtin_amdgcn_sched_barrier(0);
-            if (do_stage) stage_part(st_a, st_b, st_buf, 1 + part);
+            if (do_stage) {
+#pragma unroll
+              for (int pp = 0; pp < NPART / 4; ++pp) stage_part(st_a, st_b, st_buf, (1 + part) * (NPART / 4) + pp);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -377,8 +377,21 @@ constexpr int G2_STAGE = 2 * G2_A_BYTES;             // 64 KiB
 constexpr int G2_PAD = 4096;                          // between the two stage buffers: either buffer + the pad holds the
 constexpr int G2_BUF1 = G2_STAGE + G2_PAD;            // epilogue's 128 x 528-byte output slab
 constexpr int G2_VEC = 2048;                          // behind the stage buffers: bias / gamma of the tile's 256 columns (LNR epilogue)
-constexpr int G2_LDS = 2 * G2_STAGE + G2_PAD + G2_VEC;   // 134 KiB
 constexpr int G2_CPITCH = 528;                        // output row pitch in LDS: 256 columns x 2 B + 16 (bank shift per row)
+// Wave roles (MRAG_ENC_ROLES=1): waves 0-3 (one per SIMD) issue every LDS-DMA of the K loop, waves 4-7 every global store of
+// the epilogue.  vmcnt counts a wave's loads and stores in issue order, so a wave that does both sits out its output stores
+// (128 KiB per CU, all CUs at once: the HBM write rate) at the next stage wait; with the roles split the loading waves never
+// have a store outstanding and the storing waves never wait on vmcnt inside the K loop.
+#ifndef MRAG_ENC_ROLES
+#define MRAG_ENC_ROLES 1
+#endif
+constexpr bool G2_ROLES = MRAG_ENC_ROLES != 0;
+#ifndef MRAG_ENC_STORE_POLICY
+#define MRAG_ENC_STORE_POLICY "nt"                    // cache policy bits of the output stores (experiment: "sc1", "sc0 sc1", "")
+#endif
+constexpr int G2_CPW = G2_ROLES ? 8 : 4;              // 1-KiB chunks of each operand stage a loading wave fills
+constexpr int G2_PS = G2_ROLES ? 2048 : 0;            // roles: the loading waves' LayerNorm partial sums pass through LDS to the storing waves
+constexpr int G2_LDS = 2 * G2_STAGE + G2_PAD + G2_VEC + G2_PS;   // 134 KiB
 
 // LayerNorm folded into the GEMMs around it (LNF flags; forward_impl, "fused LayerNorm" flow):
 //   1 LNA   the A operand is the PRE-LayerNorm tensor y and W holds gamma-scaled weights W' = gamma o W:
@@ -410,7 +423,9 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
   if (stagger != 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     // > 0: XCDs apart; < 0: the workgroups of one XCD apart (blockIdx >> 3 = position inside the XCD)
+    // <= -1000000: two phase groups per XCD (positions 0-15 / 16-31), the second -(stagger + 1000000) cycles behind
     const unsigned long long wait = stagger > 0 ? (unsigned long long)(blockIdx.x & 7) * (unsigned long long)stagger
+                                    : stagger <= -1000000 ? ((blockIdx.x >> 3) >= 16 ? (unsigned long long)(-stagger - 1000000) : 0ull)
                                                 : (unsigned long long)(blockIdx.x >> 3) * (unsigned long long)(-stagger);
     while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
   }
@@ -427,19 +442,22 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
   const uint32_t voff_e = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);
   const uint32_t voff_o = (uint32_t)(lane >> 3) * row_b + (uint32_t)(((lane & 7) ^ (4 + (lane >> 4))) * 16);
   const uint32_t chunk_b = 8u * row_b;
-  const size_t wave_off = (size_t)(4 * w) * chunk_b;     // wave w fills 1-KiB chunks 4w..4w+3 of each operand
+  const bool loader = !G2_ROLES || w < 4;                // (wave-uniform)
+  const bool storer = !G2_ROLES || w >= 4;
+  const size_t wave_off = (size_t)(G2_CPW * (w & (G2_ROLES ? 3 : 7))) * chunk_b;     // wave w fills 1-KiB chunks 4w..4w+3 of each operand (roles: 8w..8w+7)
   auto tile_ptrs = [&](int lin, const char*& a, const char*& b) {
     const int tm = lin / tiles_n, tn = lin - tm * tiles_n;
     a = (const char*)(W + (size_t)tn * G2_T * K) + wave_off;
     b = (const char*)(X + (size_t)tm * G2_T * K) + wave_off;
   };
   auto stage = [&](const char* a, const char* b, int buf) {
+    if (!loader) return;
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
       const char* base = op ? b : a;
 #pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const uint32_t la = (uint32_t)(buf * G2_BUF1 + op * G2_A_BYTES + (4 * w + i) * 1024);
+      for (int i = 0; i < G2_CPW; i += 2) {
+        const uint32_t la = (uint32_t)(buf * G2_BUF1 + op * G2_A_BYTES + (G2_CPW * (w & (G2_ROLES ? 3 : 7)) + i) * 1024);
         const char* c0 = base + (size_t)i * chunk_b;
         const char* c1 = c0 + chunk_b;
         uint32_t keep;
@@ -514,8 +532,15 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   auto kstep_sync = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (G2_ROLES) {
+      if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the storing waves' output stores stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   };
 
   for (int lin = first; lin < n_tiles; lin += nwg) {
@@ -530,7 +555,7 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
       for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = EMfma<DT>::run(f1a[mf], f1b[nf], acc[mf][nf]);
     // the next tile's first stage is in flight: make sure it has landed BEFORE this tile's stores are
     // issued (vmcnt counts in order), so that the barrier below does not wait for the stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: n = tn*256 + wm*128 + mf*16 + (lane>>4)*4 + r, token = tm*256 + wn*64 + nf*16 + (lane&15).
     // The tile goes out through LDS in two passes of 128 tokens (nf = 2p, 2p+1): every lane writes its
     // 8-byte groups into a [token][column] slab (the stage buffer just consumed + the pad), then all 512
@@ -648,6 +673,38 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (G2_ROLES) {
+        // roles: the 256 threads of waves 4-7 store the slab, 16 pieces each.  Thread -> (row r0 + 8 i, piece): the piece and r0
+        // are fixed per thread, so every store is lane offset + a wave-uniform base (no per-store address registers: the
+        // hoisted 64-bit addresses of the plain loop spill).  The stores are asm so that hipcc neither counts them nor waits.
+        if (storer) {
+          const int r0 = (tid - 256) >> 5, piece = tid & 31;
+          const int n0 = tn * G2_T + piece * 8;
+          const uint32_t lane_off = ((uint32_t)r0 * (uint32_t)N + (uint32_t)(piece * 8)) * 2u;
+          const char* srow = slab + r0 * G2_CPITCH + piece * 16;
+          if (n0 < N) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 4) {          // four slab reads in flight, then their four stores
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              u32x4 vv[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const uint4 val = *(const uint4*)(srow + (g + j) * 8 * G2_CPITCH);
+                vv[j] = (u32x4){val.x, val.y, val.z, val.w};
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int i = g + j;
+                const int tok0 = tm * G2_T + (i >> 2) * 64 + pass * 32 + 8 * (i & 3);      // + r0: in lane_off
+                const char* base = (const char*)(C + (size_t)tok0 * N + (size_t)tn * G2_T);
+                if (!ENC_DBG(2))
+                  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 " MRAG_ENC_STORE_POLICY "\n\ts_nop 1" ::"v"(lane_off), "v"(vv[j]), "s"(base) : "memory");
+                else if (vv[j][0] == 0x12345678u && vv[j][1] == 0x9abcdef0u) C[0] = 1;
+              }
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = tid + G2_THR * i;                      // 128 rows x 32 sixteen-byte pieces
@@ -675,7 +732,30 @@ __global__ __launch_bounds__(G2_THR, 2) void enc_gemm256_kernel(const uint16_t* 
       for (int nf = 0; nf < 4; ++nf) {
         ps1[nf] += __shfl_xor(ps1[nf], 16); ps1[nf] += __shfl_xor(ps1[nf], 32);
         ps2[nf] += __shfl_xor(ps2[nf], 16); ps2[nf] += __shfl_xor(ps2[nf], 32);
-        if (lane < 16) ((float2*)ln.partials)[(size_t)(t_b + nf * 16) * ln.np + 2 * tn + wm] = make_float2(ps1[nf], ps2[nf]);
+      }
+      if (G2_ROLES) {
+        // waves w and w + 4 hold the two column halves (wm = 0 / 1) of the same 64 tokens: the loading wave hands its sums
+        // over through LDS and the storing wave writes both slots (the loading waves issue no global store at all)
+        float2* psl = (float2*)(sm2 + 2 * G2_STAGE + G2_PAD + G2_VEC);
+        if (!storer && lane < 16) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) psl[wn * 64 + nf * 16 + lane] = make_float2(ps1[nf], ps2[nf]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (storer && lane < 16) {
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            float2* dst = (float2*)ln.partials + (size_t)(t_b + nf * 16) * ln.np + 2 * tn;
+            dst[0] = psl[wn * 64 + nf * 16 + lane];
+            dst[1] = make_float2(ps1[nf], ps2[nf]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          if (lane < 16) ((float2*)ln.partials)[(size_t)(t_b + nf * 16) * ln.np + 2 * tn + wm] = make_float2(ps1[nf], ps2[nf]);
       }
     }
   }
@@ -1220,7 +1300,8 @@ static int run_gemm_ln(const uint16_t* A, const uint16_t* W, const float* bias, 
   const int tm2 = M_pad / G2_T, tn2 = N_pad / G2_T;
   const int cus = device_cus();   // (cached: this launcher runs ~48 times per bge-base forward)
   const int nwg = std::min(tm2 * tn2, cus);
-  hipLaunchKernelGGL((enc_gemm256_kernel<DT, EPI, LNF>), dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, W, bias, R, C, N, K, tm2, tn2, 0, ln);
+  const int stagger = (g_stagger_override != 0 && nwg % 8 == 0) ? g_stagger_override : 0;   // experiment knob, 0 in production
+  hipLaunchKernelGGL((enc_gemm256_kernel<DT, EPI, LNF>), dim3((unsigned)nwg), dim3(G2_THR), G2_LDS, stream, A, W, bias, R, C, N, K, tm2, tn2, stagger, ln);
   MRAG_HIP(hipGetLastError());
   return MRAG_OK;
 }
