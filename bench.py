@@ -243,6 +243,36 @@ def encoder_leg(device, with_cpu=False):
         cpu = {"value": nb / cpu_s, "unit": "passages/s", "cores": os.cpu_count(), "kind": "port",
                "sample": f"{nb} of the {B} passages x {S} tokens, numpy fp64 BERT forward (BLAS threads), {cpu_s:.1f} s",
                "max_abs_diff_gpu_vs_cpu": float(np.abs(got - ref).max())}
+        # HF BertModel on this host's cores via torch, same seeded weights and ids (fp32; what
+        # sentence-transformers would run on the CPU) -- only if transformers is importable on this box
+        try:
+            import torch
+            import transformers as tr
+            cfg = tr.BertConfig(vocab_size=spec["vocab_size"], hidden_size=spec["hidden"], num_hidden_layers=spec["layers"],
+                                num_attention_heads=spec["heads"], intermediate_size=spec["intermediate"],
+                                max_position_embeddings=spec["max_position"], type_vocab_size=spec["type_vocab_size"],
+                                layer_norm_eps=spec["layer_norm_eps"], hidden_act="gelu", hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0)
+            m = tr.BertModel(cfg, add_pooling_layer=False).eval()
+            sd = m.state_dict()
+            for k_, v_ in w.items():
+                if k_ in sd and tuple(sd[k_].shape) == v_.shape:
+                    sd[k_] = torch.from_numpy(np.ascontiguousarray(v_, dtype=np.float32))
+            m.load_state_dict(sd, strict=False)
+            nh = 64
+            ti, tm = torch.from_numpy(ids[:nh]).long(), torch.from_numpy(mask[:nh]).long()
+            with torch.no_grad():
+                m(input_ids=ti[:8], attention_mask=tm[:8])
+                t1 = time.perf_counter()
+                h = m(input_ids=ti, attention_mask=tm).last_hidden_state
+                hf_s = time.perf_counter() - t1
+            e = h[:, 0] if a["pool"] == "cls" else (h * tm[:, :, None]).sum(1) / tm.sum(1, keepdim=True).clamp(min=1e-9)
+            e = torch.nn.functional.normalize(e, dim=1).numpy()
+            cpu["hf_torch"] = {"value": nh / hf_s, "unit": "passages/s", "torch_threads": torch.get_num_threads(),
+                               "sample": f"{nh} of the {B} passages x {S} tokens, transformers.BertModel fp32 on the CPU, {hf_s:.1f} s",
+                               "max_abs_diff_gpu_vs_hf": float(np.abs(enc.forward(ids[:nh], mask[:nh]) - e).max())}
+        except Exception as ex:      # transformers absent on this box: the numpy port above stays the baseline
+            cpu["hf_torch"] = {"skipped": repr(ex)}
     enc.close()
     return {"bound": "mfma", "cpu_baseline": cpu, "kernel": "enc_gemm256_kernel (LayerNorm folded into its epilogues) + enc_attention_s128_kernel (whole forward)",
             "workload": f"C3 shape: {arch}, {B} passages x {S} tokens, seeded weights",
