@@ -37,7 +37,6 @@ struct IvfIndex : Object {
   int max_list_rows = 0;
   DevBuf qbuf, qg, lists, counts, stage_in, tmp_sc, tmp_id, out_sc, out_id, desc, ploc, gq, perm, sums, cnts;
   DevBuf d_list_count, d_list_tile_lo, plan;   // device copies of the list layout; plan = lcount | wg_first | cursor | n_wg
-  DevBuf gsoff;                                // score-segment regime: float offset of every query group's score block
   DevBuf scores, sdesc;                        // "score segments + select" regime (ivf_scan.hip): fp32 segments, dense descriptors
   bool last_scores_path = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start | (unused) | (unused) | search end
@@ -49,7 +48,7 @@ struct IvfIndex : Object {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : cev) if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)cen, (void*)raw, (void*)assign, (void*)sorted, (void*)row_ids}) if (p) (void)hipFree(p);
-    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc, &stats, &gsoff}) b->release();
+    for (DevBuf* b : {&qbuf, &qg, &lists, &counts, &stage_in, &tmp_sc, &tmp_id, &out_sc, &out_id, &desc, &ploc, &gq, &perm, &sums, &cnts, &d_list_count, &d_list_tile_lo, &plan, &scores, &sdesc, &stats}) b->release();
   }
 };
 
@@ -134,10 +133,13 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const int* __restrict__ 
   }
 }
 
+// (score-segment regime, pinfo != nullptr: the thread that draws slot 0 of a query group also writes the group's scan
+// descriptors -- one per IVFS_CHUNK_ROWS rows of the list --, so the single-workgroup plan kernel only runs the prefix sums)
 __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t npairs, int nprobe,
                                    const int* __restrict__ list_count, const int* __restrict__ wg_first,
                                    int* __restrict__ cursor, int64_t* __restrict__ gq, int2* __restrict__ ploc, int qshift,
-                                   const long long* __restrict__ gsoff, const int* __restrict__ list_tile_lo, int4* __restrict__ pinfo) {
+                                   const long long* __restrict__ foff, const int* __restrict__ list_tile_lo, int4* __restrict__ pinfo,
+                                   const int* __restrict__ lcount, const int* __restrict__ dfirst, int* __restrict__ desc, int desc_cap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npairs) return;
   const int64_t l = probes[i];
@@ -152,10 +154,23 @@ __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t n
     // score-segment regime: everything the per-query selection needs about this pair, in one 16-byte record -- its score
     // segment (its group's block + slot x pitch), the rows and the first stored row of the whole LIST (the list's rows may be
     // cut over several scan descriptors; every one of them writes its rows of this segment)
-    const int lc = list_count[l];
+    const int lc = list_count[l], grp = pos >> qshift, tlo = list_tile_lo[l];
     const long long pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
-    const long long so = gsoff[wgi] + (long long)slot * pitch;
-    pinfo[i] = make_int4((int)(unsigned)(so & 0xFFFFFFFFll), (int)(so >> 32), lc, list_tile_lo[l] * 256);
+    const long long gso = foff[l] + (long long)grp * IVFS_QUERIES * pitch;      // the group's score block
+    const long long so = gso + (long long)slot * pitch;
+    pinfo[i] = make_int4((int)(unsigned)(so & 0xFFFFFFFFll), (int)(so >> 32), lc, tlo * 256);
+    if (slot == 0) {
+      const int cnt = lcount[l], nch = (lc + IVFS_CHUNK_ROWS - 1) / IVFS_CHUNK_ROWS;
+      for (int r = 0; r < nch; ++r) {
+        const int di = dfirst[l] + grp * nch + r;
+        if (di < desc_cap) {
+          int4* d = (int4*)(desc + (size_t)di * IVFS_DESC_WORDS);
+          d[0] = make_int4(wgi * IVFS_QUERIES, min(IVFS_QUERIES, cnt - grp * IVFS_QUERIES), tlo * 256 + r * IVFS_CHUNK_ROWS,
+                           min(IVFS_CHUNK_ROWS, lc - r * IVFS_CHUNK_ROWS));
+          d[1] = make_int4(r * IVFS_CHUNK_ROWS, (int)(unsigned)(gso & 0xFFFFFFFFll), (int)(gso >> 32), (int)pitch);
+        }
+      }
+    }
   } else {
     ploc[i] = make_int2(wgi, slot);
   }
@@ -168,21 +183,21 @@ __global__ void ivf_scatter_kernel(const int64_t* __restrict__ probes, int64_t n
 // Measured (round 3, one box, whole search): chunk = whole list / 1024 / 512 / 256 / 128 rows -- C5 share (152-row lists) 0.743 /
 // - / 0.743 / 0.713 / 0.700 ms; 5 M rows (1 220-row lists) 4.02 / 3.81 / 3.64 / 3.51 / 3.56 ms; Zipf-sized lists (0 ... 5 330 rows),
 // nprobe 1 / 32: 0.98 / 1.38 -> 0.62 / 1.13 -> 0.61 / 1.05 -> 0.52 / 0.94 -> 0.50 / 0.94 ms.
-// out[0] = descriptors, out[1..2] = score floats; gsoff[group] = float offset of the group's block; wg_first[l] = first group.
+// out[0] = descriptors, out[1..2] = score floats; per list: wg_first = first group, dfirst = first descriptor, foff = float offset of its score blocks.
 __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __restrict__ lcount, const int* __restrict__ list_count,
-                                                               const int* __restrict__ list_tile_lo, int nlist,
-                                                               int* __restrict__ wg_first, int* __restrict__ cursor,
-                                                               int* __restrict__ desc, int desc_cap, int* __restrict__ out,
-                                                               unsigned long long* __restrict__ stats, long long* __restrict__ gsoff,
-                                                               int group_cap) {
-  __shared__ int part[1024];          // groups
-  __shared__ int dpart[1024];         // descriptors
-  __shared__ long long fpart[1024];   // score floats
-  __shared__ int carry, dcarry;
-  __shared__ long long fcarry;
+                                                               int nlist, int* __restrict__ wg_first, int* __restrict__ cursor,
+                                                               int* __restrict__ dfirst, long long* __restrict__ foff,
+                                                               int* __restrict__ out, unsigned long long* __restrict__ stats) {
+  // three exclusive prefix sums over the lists (query groups, scan descriptors, score floats): wave scans by shuffles, the 16
+  // wave totals through LDS -- two barriers per 1024 lists (the Hillis-Steele form took 20 per sum and wrote every descriptor
+  // from this one workgroup: 37 us at the C5 share, 86 us over 5 M rows; the descriptors are now written by ivf_scatter_kernel)
+  __shared__ int wt_g[16], wt_d[16];
+  __shared__ long long wt_f[16];
   __shared__ unsigned long long rows_acc;
-  const int tid = threadIdx.x;
-  if (tid == 0) { carry = 0; dcarry = 0; fcarry = 0; rows_acc = 0ull; }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int carry = 0, dcarry = 0;
+  long long fcarry = 0;
+  if (tid == 0) rows_acc = 0ull;
   __syncthreads();
   for (int base = 0; base < nlist; base += 1024) {
     const int l = base + tid;
@@ -193,49 +208,32 @@ __global__ __launch_bounds__(1024) void ivf_plan_scores_kernel(const int* __rest
     if (nt && lc) atomicAdd(&rows_acc, (unsigned long long)nt * (unsigned long long)lc);   // rows this list's workgroups stream
     const int pitch = (lc + IVFS_PITCH_ALIGN - 1) / IVFS_PITCH_ALIGN * IVFS_PITCH_ALIGN;
     const long long fl = (long long)cnt * pitch;
-    part[tid] = nt;
-    dpart[tid] = nt * nch;
-    fpart[tid] = fl;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {           // inclusive scans (Hillis-Steele)
-      const int v = tid >= off ? part[tid - off] : 0;
-      const int dv = tid >= off ? dpart[tid - off] : 0;
-      const long long fv = tid >= off ? fpart[tid - off] : 0;
-      __syncthreads();
-      part[tid] += v;
-      dpart[tid] += dv;
-      fpart[tid] += fv;
-      __syncthreads();
+    int ig = nt, id = nt * nch;
+    long long iff = fl;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int vg = __shfl_up(ig, off), vd = __shfl_up(id, off);
+      const long long vf = __shfl_up(iff, off);
+      if (lane >= off) { ig += vg; id += vd; iff += vf; }
     }
-    const int first = carry + part[tid] - nt;
-    const int dfirst = dcarry + dpart[tid] - nt * nch;
-    const long long foff = fcarry + fpart[tid] - fl;
+    if (lane == 63) { wt_g[w] = ig; wt_d[w] = id; wt_f[w] = iff; }
+    __syncthreads();
+    int bg = 0, bd = 0, tg = 0, td = 0;
+    long long bf = 0, tf = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int g_ = wt_g[i], d_ = wt_d[i];
+      const long long f_ = wt_f[i];
+      if (i < w) { bg += g_; bd += d_; bf += f_; }
+      tg += g_; td += d_; tf += f_;
+    }
     if (l < nlist) {
-      wg_first[l] = first;
+      wg_first[l] = carry + bg + ig - nt;
+      dfirst[l] = dcarry + bd + id - nt * nch;
+      foff[l] = fcarry + bf + iff - fl;
       cursor[l] = 0;
-      const int tlo = list_tile_lo[l];
-      for (int c = 0; c < nt; ++c) {
-        const long long so = foff + (long long)c * IVFS_QUERIES * pitch;
-        if (first + c < group_cap) gsoff[first + c] = so;
-        for (int r = 0; r < nch; ++r) {
-          const int di = dfirst + c * nch + r;
-          if (di < desc_cap) {
-            int* d = desc + (size_t)di * IVFS_DESC_WORDS;
-            d[0] = (first + c) * IVFS_QUERIES;
-            d[1] = min(IVFS_QUERIES, cnt - c * IVFS_QUERIES);
-            d[2] = tlo * 256 + r * IVFS_CHUNK_ROWS;
-            d[3] = min(IVFS_CHUNK_ROWS, lc - r * IVFS_CHUNK_ROWS);
-            d[4] = r * IVFS_CHUNK_ROWS;
-            d[5] = (int)(unsigned)(so & 0xFFFFFFFFll);
-            d[6] = (int)(so >> 32);
-            d[7] = pitch;
-          }
-        }
-      }
     }
-    __syncthreads();
-    if (tid == 1023) { carry += part[1023]; dcarry += dpart[1023]; fcarry += fpart[1023]; }
-    __syncthreads();
+    carry += tg; dcarry += td; fcarry += tf;     // (every thread keeps the same running totals)
+    __syncthreads();                             // the wave totals are rewritten by the next 1024 lists
   }
   if (tid == 0) {
     out[0] = dcarry;
@@ -587,11 +585,13 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   // GEMM + top-k kernel in descriptor mode.  MRAG_IVF_SCORES_MB = 0 forces the fused path (tests).
   static const int64_t scores_cap = [] { const char* e = getenv("MRAG_IVF_SCORES_MB"); return (int64_t)(e ? atoll(e) : 16384) << 20; }();
   const int nl = ix->nlist;
-  MRAG_TRY(ix->plan.ensure((size_t)(3 * nl + 4) * 4));
-  int* d_lcount = (int*)ix->plan.p;      // queries per list | first workgroup of the list | cursor | workgroup count, score floats
+  MRAG_TRY(ix->plan.ensure((size_t)(4 * nl + 4) * 4 + (size_t)nl * 8));
+  int* d_lcount = (int*)ix->plan.p;      // queries per list | first group of the list | cursor | first descriptor | descriptor count, score floats | float offset of the list's score blocks
   int* d_wg_first = d_lcount + nl;
   int* d_cursor = d_wg_first + nl;
-  int* d_nwg = d_cursor + nl;
+  int* d_dfirst = d_cursor + nl;
+  int* d_nwg = d_dfirst + nl;
+  long long* d_foff = (long long*)(d_nwg + 4);
   MRAG_HIP(hipMemsetAsync(d_lcount, 0, (size_t)nl * 4, stream));
   bool counted = false;                  // the probe selection below can fill d_lcount itself
   if (nprobe == ix->nlist) {
@@ -621,7 +621,6 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   const int64_t desc_bound = wg_bound * std::max<int64_t>(1, (ix->max_list_rows + IVFS_CHUNK_ROWS - 1) / IVFS_CHUNK_ROWS);
   MRAG_TRY(ix->desc.ensure((size_t)desc_bound * 8 * 4));
   MRAG_TRY(ix->gq.ensure((size_t)wg_bound * 256 * 8));
-  MRAG_TRY(ix->gsoff.ensure((size_t)wg_bound * 8));
   MRAG_TRY(ix->ploc.ensure(npairs * 16));   // int2 (fused regime) or int4 (score segments) per pair
   const unsigned pgrid = (unsigned)((npairs + 255) / 256);
   if (!counted)
@@ -637,8 +636,7 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   const bool planned_scores = use_scores;
   if (use_scores) {
     hipLaunchKernelGGL(ivf_plan_scores_kernel, dim3(1), dim3(1024), 0, stream, (const int*)d_lcount, (const int*)ix->d_list_count.p,
-                       (const int*)ix->d_list_tile_lo.p, nl, d_wg_first, d_cursor, (int*)ix->desc.p, (int)desc_bound, d_nwg, d_stats,
-                       (long long*)ix->gsoff.p, (int)wg_bound);
+                       nl, d_wg_first, d_cursor, d_dfirst, d_foff, d_nwg, d_stats);
     MRAG_HIP(hipGetLastError());
     if (no_sync) {
       MRAG_TRY(ix->scores.ensure((size_t)std::max<int64_t>((int64_t)npairs * max_pitch, 4) * 4));
@@ -655,7 +653,8 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
   if (use_scores) {
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, nullptr, 7,
-                       (const long long*)ix->gsoff.p, (const int*)ix->d_list_tile_lo.p, (int4*)ix->ploc.p);
+                       (const long long*)d_foff, (const int*)ix->d_list_tile_lo.p, (int4*)ix->ploc.p, (const int*)d_lcount,
+                       (const int*)d_dfirst, (int*)ix->desc.p, (int)desc_bound);
     MRAG_HIP(hipGetLastError());
     // 3) scores of every (query, probed list) pair, then the k best per query
     MRAG_HIP(hipEventRecord(ev_scan0, stream));
@@ -685,7 +684,7 @@ static int ivf_search_chunk(IvfIndex* ix, const void* queries, int64_t nq, int q
                        planned_scores ? nullptr : d_stats);   // (a scores plan that turned out too big has already counted this chunk)
     hipLaunchKernelGGL(ivf_scatter_kernel, dim3(pgrid), dim3(256), 0, stream, (const int64_t*)ix->tmp_id.p, (int64_t)npairs, nprobe,
                        (const int*)ix->d_list_count.p, (const int*)d_wg_first, d_cursor, (int64_t*)ix->gq.p, (int2*)ix->ploc.p, 8,
-                       nullptr, nullptr, nullptr);
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     MRAG_HIP(hipGetLastError());
     MRAG_HIP(hipMemcpyAsync(&n_wg, d_nwg, 4, hipMemcpyDeviceToHost, stream));
     MRAG_HIP(hipStreamSynchronize(stream));

@@ -104,6 +104,12 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
   // the 16-byte piece a lane fetches is XOR-swizzled by its row so that the fragment reads are conflict-free
   const uint16_t* a_src[4];
   const uint16_t* b_src[4];
+  int64_t qid[4];                                            // the four query-row ids this lane gathers: all four loads in flight together
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (4 * w + i) * 8 + (lane >> 3);
+    qid[i] = (gq_base >= 0 && !IVFS_DBG(4) && r < nq_local) ? gq[(size_t)gq_base + r] : -1;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (4 * w + i) * 8 + (lane >> 3);
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(STHR) void ivfs_scan_kernel(const uint16_t* __restr
     int64_t qrow;
     if (gq_base < 0) qrow = (int64_t)(-1 - gq_base) + r;                 // identity: queries first .. first + 127 (the buffer is padded)
     else if (IVFS_DBG(4)) qrow = r;
-    else { qrow = r < nq_local ? gq[(size_t)gq_base + r] : -1; if (qrow < 0) qrow = zero_row; }
+    else { qrow = qid[i]; if (qrow < 0) qrow = zero_row; }
     b_src[i] = queries + (size_t)qrow * ld + kc * 8;
   }
   const int n_steps = n_tiles * nk;
