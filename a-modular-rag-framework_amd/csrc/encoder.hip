@@ -56,7 +56,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
   const float h = 0.5f * p * t * __expf(-ax * ax);     // 0.5 * erfc(|x|/sqrt 2)
-  return v >= 0.f ? v - v * h : v * h;
+  // v >= 0: v - v h;  v < 0: v h = -|v| h  ==  max(v, 0) - |v| h for both signs (same roundings as the two-branch form:
+  // one fma / one product), without the compare + select per element (a v_cmp into an SGPR pair, a wait state, a v_cndmask)
+  return fmaf(-fabsf(v), h, fmaxf(v, 0.f));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
