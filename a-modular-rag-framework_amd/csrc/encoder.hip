@@ -49,15 +49,17 @@ template <> struct EMfma<MRAG_BF16> {
 // value in fp32, three orders below the fp16 rounding of the stored activation): ~13 VALU ops instead
 // of libm erff's ~40 -- at K = 768 the FFN-up epilogue is as long as its MFMA loop otherwise.
 __device__ __forceinline__ float gelu_erf(float v) {
-  const float ax = fabsf(v) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float h = 0.5f * p * t * __expf(-ax * ax);     // 0.5 * erfc(|x|/sqrt 2)
-  // v >= 0: v - v h;  v < 0: v h = -|v| h  ==  max(v, 0) - |v| h for both signs (same roundings as the two-branch form:
-  // one fma / one product), without the compare + select per element (a v_cmp into an SGPR pair, a wait state, a v_cndmask)
+  // constants folded: b = |v| sqrt(log2 e / 2) so that exp(-v^2 / 2) = exp2(-b^2) (no separate log2 e multiply), the
+  // 0.3275911 of t = 1 / (1 + 0.3275911 |v| / sqrt 2) rescaled to b, the 0.5 of 0.5 erfc folded into the polynomial
+  const float b = fabsf(v) * 0.84932180028801904f;                     // sqrt(log2(e) / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.27273748087922250f, b, 1.0f));   // 0.3275911 / sqrt(log2 e)
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float h = p * t * __builtin_amdgcn_exp2f(-b * b);              // 0.5 * erfc(|v| / sqrt 2)
+  // v >= 0: v - v h;  v < 0: v h = -|v| h  ==  max(v, 0) - |v| h for both signs (one fma), without a compare + select per
+  // element (a v_cmp into an SGPR pair, a wait state, a v_cndmask)
   return fmaf(-fabsf(v), h, fmaxf(v, 0.f));
 }
 
